@@ -1,0 +1,243 @@
+/*
+ * psg_hip.h — C ABI of libpsg_hip.so: the MI355X (gfx950) kernels behind the
+ * U-Net denoising train step of GabrieleConte/pokemon-sprite-generator.
+ *
+ * The reference has NO native code, plugin registry or FFI: its hot path is
+ * PyTorch ATen ops called from src/models/unet.py and
+ * src/training/improved_diffusion_trainer.py.  Each entry point below replaces
+ * the ATen call(s) made at the cited reference lines (paths relative to the
+ * reference root).  The host side (the .py files of pokemon_sprite_generator_amd) binds
+ * these with ctypes; INTEGRATION.md shows the stub.
+ *
+ * Conventions
+ *  - Plain pointers and sizes only; no torch types.  All pointers are DEVICE
+ *    pointers borrowed for the duration of the call.  Nothing is allocated or
+ *    freed on behalf of the caller: scratch is a caller-provided workspace
+ *    (query *_workspace_bytes first).
+ *  - Every launch is asynchronous on `stream` (a hipStream_t); no hidden
+ *    synchronisation, no host reads: graph-capture safe.
+ *  - Return 0 on success, <0 on error (enum below); psg_last_error() returns a
+ *    thread-local message.  NaN/Inf in data is reported as data (flags), never
+ *    as an error.
+ *  - Activations are channels-last: a [B, H, W, C] (or [B, L, C] token) tensor
+ *    is a row-major matrix of B*H*W rows with an explicit row stride `ld`
+ *    (in elements), so slices of wider buffers are addressable.  dtype selects
+ *    the element type of activations and prepared weights (PSG_F32 / PSG_BF16);
+ *    statistics, biases, accumulators, master weights and gradients of
+ *    parameters are always fp32.
+ */
+#ifndef PSG_HIP_H
+#define PSG_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* psg_stream_t; /* hipStream_t */
+
+enum psg_status {
+    PSG_OK = 0,
+    PSG_ERR_SHAPE = -1,
+    PSG_ERR_DTYPE = -2,
+    PSG_ERR_ALIGN = -3,
+    PSG_ERR_WORKSPACE = -4,
+    PSG_ERR_HIP = -5,
+    PSG_ERR_ARG = -6
+};
+enum psg_dtype { PSG_F32 = 0, PSG_BF16 = 1 };
+enum psg_act { PSG_ACT_NONE = 0, PSG_ACT_SILU = 1, PSG_ACT_GELU = 2 };
+
+const char* psg_last_error(void);
+int psg_version(void);
+/* Select device, raise LDS limits of the big kernels.  Idempotent. */
+int psg_init(int device);
+
+/* ---------------------------------------------------------------------------
+ * Noise schedule / sampler elementwise ops (bit-exact fp32, contraction off)
+ * ------------------------------------------------------------------------- */
+
+/* NoiseScheduler.add_noise — improved_diffusion_trainer.py:50-65 (+ clamp :363).
+ * out[b,i] = tabA[t[b]] * clamp?(x0[b,i]) + tabB[t[b]] * noise[b,i]; two rounded
+ * multiplies and one rounded add, bit-identical to the CPU path.  *flag (int32,
+ * device) is OR-ed with 1 if any output is NaN/Inf, with 2 if any t[b] is
+ * outside [0,num_t).  Zero *flag before the call. */
+int psg_noise_add_f32(const float* x0, const float* noise, const int64_t* t, const float* tabA,
+                      const float* tabB, float* out, int32_t* flag, int64_t B, int64_t chw,
+                      int num_t, int do_clamp, psg_stream_t stream);
+/* The reference's fallback (:61-63): if (*flag & 1) out = clamp?(x0) + 0.1*noise.  Device-side
+ * test of the flag; no host sync. */
+int psg_noise_fallback_f32(const float* x0, const float* noise, float* out, const int32_t* flag,
+                           int64_t n, int do_clamp, psg_stream_t stream);
+/* ddpm_sample update — improved_diffusion_trainer.py:543-567.  step tables hold the per-timestep
+ * scalars c1=1/sqrt(alpha_t), c2=beta_t/sqrt(1-alphabar_t), sigma=sqrt(beta_t) (fp32, computed on
+ * the host with the reference's torch ops); t_index selects the entry on the device so the launch
+ * is graph-replayable: x <- c1*(x - c2*eps) [+ sigma*z if t>0].  t_dev: int32 device scalar. */
+int psg_ddpm_update_f32(float* x, const float* eps, const float* z, const float* c1, const float* c2,
+                        const float* sigma, const int32_t* t_dev, int64_t n, psg_stream_t stream);
+
+/* SmoothL1Loss(beta) mean + its gradient — improved_diffusion_trainer.py:300,388,396.
+ * loss_out: fp32 device scalar; grad (may be NULL) = dL/dpred * grad_scale.  Deterministic
+ * two-stage reduction.  ws: >= psg_reduce_workspace_bytes() bytes. */
+int psg_smooth_l1_f32(const float* pred, const float* target, float* grad, float* loss_out,
+                      int32_t* nan_flag, float beta, float grad_scale, int64_t n, void* ws,
+                      psg_stream_t stream);
+int64_t psg_reduce_workspace_bytes(void);
+
+/* ---------------------------------------------------------------------------
+ * Layout / small ops at the boundary (NCHW fp32 <-> channels-last dtype)
+ * ------------------------------------------------------------------------- */
+/* [B,C,HW] fp32 -> [B,HW,C] dtype (UNet.forward input, unet.py:448) and back (:507-509). */
+int psg_nchw_to_nhwc(const float* src, void* dst, int64_t ld_dst, int B, int C, int HW, int dtype,
+                     psg_stream_t stream);
+int psg_nhwc_to_nchw(const void* src, int64_t ld_src, float* dst, int B, int C, int HW, int dtype,
+                     psg_stream_t stream);
+/* AdaptiveAvgPool1d(1) over tokens — unet.py:322,445: text [B,S,D] fp32 -> out[B, :D] (dtype),
+ * and the dtype copy of the token embeddings themselves (text_cast, may be NULL). */
+int psg_text_pool(const float* text, void* pooled, int64_t ld_pooled, void* text_cast, int B, int S,
+                  int D, int dtype, psg_stream_t stream);
+/* Sinusoidal features — unet.py:47-50: out[b, :half]=sin(t*coeff), out[b, half:]=cos(t*coeff),
+ * accurate sinf/cosf (arguments reach 999 rad). */
+int psg_timestep_sinusoid(const int64_t* t, const float* coeff, void* out, int64_t ld_out, int B,
+                          int half, int dtype, psg_stream_t stream);
+/* nn.Upsample(size, bilinear, align_corners=False) — unet.py:365,375,385, channels-last. */
+int psg_upsample_bilinear_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, int B, int Hi, int Wi,
+                              int Ho, int Wo, int C, int dtype, psg_stream_t stream);
+int psg_upsample_bilinear_bwd(const void* dy, int64_t lddy, void* dx, int64_t lddx, int B, int Hi,
+                              int Wi, int Ho, int Wo, int C, int dtype, psg_stream_t stream);
+/* y = a + b (elementwise, strided rows); used for gradient fan-in of skip tensors. */
+int psg_add(const void* a, int64_t lda, const void* b, int64_t ldb, void* y, int64_t ldy, int64_t rows,
+            int cols, int dtype, psg_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * GroupNorm (+ fused SiLU) — unet.py:79,89,115,127,397 (eps 1e-5) and
+ * :156-157,214,231 (eps 1e-6 on [B,C,L]); channels-last [B, HW, C].
+ * mean/rstd: fp32 [B*G].  Biased variance, eps inside the sqrt.
+ * ------------------------------------------------------------------------- */
+int psg_groupnorm_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, const float* gamma,
+                      const float* beta, float* mean, float* rstd, int B, int HW, int C, int G,
+                      float eps, int silu, int dtype, psg_stream_t stream);
+/* dx (may alias dy), dgamma/dbeta fp32 [C] (overwritten, or accumulated if accumulate!=0).
+ * ws: >= psg_groupnorm_bwd_workspace_bytes(B,C) bytes. */
+int psg_groupnorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* gamma,
+                      const float* beta, const float* mean, const float* rstd, void* dx, int64_t lddx,
+                      float* dgamma, float* dbeta, int B, int HW, int C, int G, int silu, int accumulate,
+                      int dtype, void* ws, psg_stream_t stream);
+int64_t psg_groupnorm_bwd_workspace_bytes(int B, int C);
+
+/* ---------------------------------------------------------------------------
+ * Implicit-GEMM convolution / linear on MFMA — nn.Conv2d 3x3 s1/s2 p1 and 1x1
+ * (unet.py:80,90,96,325,335,342,349,366,376,386,399) and every nn.Linear
+ * (unet.py:28-34,83,86,176,181-187 and the MHA in/out projections :160-173).
+ *
+ *   y[m, n] = residual[m, n] + alpha * drop(act(acc[m, n] + bias[n] + rowadd[b(m), n])) * dact'(...)
+ *   acc[m, n] = sum_{kh,kw,ci} x[pix(m,kh,kw), ci] * w[n, (kh,kw,ci)]
+ *
+ * m indexes output pixels (b, ho, wo) row-major; a Linear is ksize=1, H=W=1.
+ * `w` is a PREPARED weight [N][Kpad] (psg_prep_weight), Kpad = K rounded up to
+ * the kernel's K tile.  transposed=1 gathers as the data-gradient of a strided
+ * conv (x is then dY on the [Hi,Wi] grid of the forward OUTPUT, the result lives
+ * on the forward INPUT grid [Ho,Wo]); with a dgrad-prepared weight this is
+ * conv2d's dgrad for any stride.
+ * ------------------------------------------------------------------------- */
+typedef struct psg_conv_desc {
+    int32_t dtype;               /* psg_dtype of x, w, y, rowadd, residual, preact, dact_u */
+    int32_t B, Hi, Wi, Cin;      /* gather source x: [B, Hi, Wi, Cin] */
+    int32_t Ho, Wo, Cout;        /* result y: [B, Ho, Wo, Cout] */
+    int32_t ksize, stride, pad;  /* 1 or 3; 1 or 2; 0 or 1 */
+    int32_t transposed;          /* 0 forward gather, 1 data-gradient gather */
+    int32_t act;                 /* psg_act applied to (acc + bias + rowadd) */
+    float alpha;                 /* scale of the activated value (gates 0.7/0.8/0.6: unet.py:220,238,250) */
+    float drop_p;                /* dropout probability on the activated value (0 = off) */
+    uint64_t drop_seed;          /* mask = hash(seed, m*Cout+n) — regenerated in backward */
+    int64_t ldx, ldy, ld_rowadd, ld_residual, ld_preact, ld_dact;
+    int64_t ldw;                 /* row stride of w in elements; 0 = Kpad (a column slice of a wider prepared
+                                    weight is addressed with w + offset and ldw = its Kpad) */
+    const void* x;
+    const void* w;
+    void* y;
+    const float* bias;           /* [Cout] fp32 or NULL */
+    const void* rowadd;          /* [B, Cout] per-sample add (time/text proj, unet.py:119-124) or NULL */
+    const void* residual;        /* [M, Cout] or NULL; may alias y (accumulate) */
+    void* preact;                /* optional store of (acc+bias+rowadd) for backward, or NULL */
+    const void* dact_u;          /* backward form: when non-NULL, `act` is NOT applied; the value is multiplied by
+                                    act'(dact_u[m,n]) (saved pre-activation) and by the same dropout mask */
+} psg_conv_desc;
+int psg_conv_fwd(const psg_conv_desc* d, psg_stream_t stream);
+
+/* Weight gradient — convolution_backward's wgrad for the same layers.
+ * dw[co][ci][kh][kw] (fp32, OIHW like the parameter) = sum_m dy[m,co] * x[pix(m,kh,kw), ci]
+ * (overwritten, or accumulated if accumulate != 0).  Split-K over pixels with a
+ * deterministic second pass.  ws: >= psg_conv_wgrad_workspace_bytes(...). */
+typedef struct psg_wgrad_desc {
+    int32_t dtype;
+    int32_t B, Hi, Wi, Cin, Ho, Wo, Cout, ksize, stride, pad;
+    int32_t accumulate;
+    int64_t ldx, lddy;
+    const void* x;    /* forward input  [B,Hi,Wi,Cin] */
+    const void* dy;   /* output grad    [B,Ho,Wo,Cout] */
+    float* dw;        /* [Cout, Cin, k, k] fp32 */
+    void* ws;
+    int64_t ws_bytes;
+} psg_wgrad_desc;
+int psg_conv_wgrad(const psg_wgrad_desc* d, psg_stream_t stream);
+int64_t psg_conv_wgrad_workspace_bytes(const psg_wgrad_desc* d);
+
+/* fp32 OIHW master weight -> prepared forward weight wf [O][Kpad] with k=(kh,kw,ci) and prepared
+ * data-gradient weight wd [I][Kpad'] with k=(kh,kw,co) (either may be NULL); zero K padding.
+ * Returns Kpad for (ksize*ksize*C) via psg_kpad(). */
+int psg_prep_weight(const float* w, void* wf, void* wd, int O, int I, int ksize, int dtype,
+                    psg_stream_t stream);
+int64_t psg_kpad(int64_t K, int dtype);
+
+/* Column sums: out[g, c] = sum_{r<R} a[(g*R + r), c] for g<groups.  groups=1 gives a bias
+ * gradient (fp32 out); groups=B, R=HW gives the gradient of the per-sample rowadd.  out_dtype
+ * selects fp32 or bf16 output; accumulate adds into out (fp32 only).  Deterministic. */
+int psg_colsum(const void* a, int64_t lda, void* out, int64_t ld_out, int64_t R, int groups, int cols,
+               int dtype, int out_dtype, int accumulate, void* ws, int64_t ws_bytes, psg_stream_t stream);
+int64_t psg_colsum_workspace_bytes(int64_t R, int groups, int cols);
+
+/* Backward of the psg_conv_fwd epilogue: g[m,n] = dy[m,n] * alpha * mask(seed, m*cols+n)/(1-p) * act'(u[m,n])
+ * (u = saved pre-activation, may be NULL when act == PSG_ACT_NONE). */
+int psg_epilogue_bwd(const void* dy, int64_t lddy, const void* u, int64_t ldu, void* g, int64_t ldg, int64_t rows,
+                     int cols, int act, float alpha, float drop_p, uint64_t seed, int dtype, psg_stream_t stream);
+/* dropout backward helper: y = x * mask(seed, idx) * scale (same hash as psg_conv_fwd). */
+int psg_dropout_apply(const void* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int cols,
+                      float p, uint64_t seed, float scale, int dtype, psg_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Multi-head attention core — the scaled-dot-product inside
+ * nn.MultiheadAttention (unet.py:160-173,217,235; torch/nn/functional.py
+ * multi_head_attention_forward): P = softmax((q/sqrt(d)) k^T), o = drop(P) v.
+ * q rows: token (b,l) at q + (b*L+l)*ldq + h*d; k, v: (b,s) at + (b*S+s)*ldk.
+ * lse: fp32 [B, heads, L] (log-sum-exp of the scaled scores) saved for backward.
+ * ------------------------------------------------------------------------- */
+int psg_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                 void* o, int64_t ldo, float* lse, int B, int heads, int L, int S, int d, float scale,
+                 float drop_p, uint64_t seed, int dtype, psg_stream_t stream);
+/* delta: fp32 [B, heads, L] scratch.  dq/dk/dv have the strides of q/k/v. */
+int psg_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
+                 const void* o, int64_t ldo, const void* dout, int64_t lddo, const float* lse,
+                 float* delta, void* dq, int64_t lddq, void* dk, int64_t lddk, void* dv, int64_t lddv,
+                 int B, int heads, int L, int S, int d, float scale, float drop_p, uint64_t seed,
+                 int dtype, psg_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * Optimizer side — improved_diffusion_trainer.py:399-413
+ * ------------------------------------------------------------------------- */
+/* out[0] (+)= sum(g^2) over n fp32 values; deterministic.  Replaces the 478 .item() syncs (:399-404). */
+int psg_sumsq_f32(const float* g, int64_t n, float* out, int accumulate, void* ws, psg_stream_t stream);
+/* clip_grad_norm_ (:410) fused with AdamW (:277-283,412): coef = min(1, max_norm/(sqrt(*normsq)+1e-6))
+ * read on the device (normsq may be NULL = no clipping); decoupled weight decay; step is 1-based.
+ * skip_flag (may be NULL): when *skip_flag != 0 the update is skipped (NaN batch, :383-393). */
+int psg_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, const float* normsq,
+                  float max_norm, const int32_t* skip_flag, psg_stream_t stream);
+/* g *= min(1, max_norm/(sqrt(*normsq)+1e-6)) — plain clip for callers that keep torch.optim. */
+int psg_clip_scale_f32(float* g, int64_t n, const float* normsq, float max_norm, psg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSG_HIP_H */

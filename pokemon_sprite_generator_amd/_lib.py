@@ -1,0 +1,154 @@
+"""ctypes binding of libpsg_hip.so (the C ABI declared in include/psg_hip.h).
+
+The product path has NO fallback: if the shared library is missing, any attempt
+to run an op raises (``load()``), it never reroutes to a CPU or eager path.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpsg_hip.so")
+
+PSG_F32, PSG_BF16 = 0, 1
+ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
+
+c_void_p, c_int, c_int64, c_float, c_uint64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
+
+
+class ConvDesc(C.Structure):
+    """struct psg_conv_desc (include/psg_hip.h)."""
+    _fields_ = [
+        ("dtype", C.c_int32), ("B", C.c_int32), ("Hi", C.c_int32), ("Wi", C.c_int32), ("Cin", C.c_int32),
+        ("Ho", C.c_int32), ("Wo", C.c_int32), ("Cout", C.c_int32),
+        ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+        ("transposed", C.c_int32), ("act", C.c_int32),
+        ("alpha", C.c_float), ("drop_p", C.c_float), ("drop_seed", C.c_uint64),
+        ("ldx", C.c_int64), ("ldy", C.c_int64), ("ld_rowadd", C.c_int64), ("ld_residual", C.c_int64),
+        ("ld_preact", C.c_int64), ("ld_dact", C.c_int64), ("ldw", C.c_int64),
+        ("x", c_void_p), ("w", c_void_p), ("y", c_void_p), ("bias", c_void_p), ("rowadd", c_void_p),
+        ("residual", c_void_p), ("preact", c_void_p), ("dact_u", c_void_p),
+    ]
+
+
+class WgradDesc(C.Structure):
+    """struct psg_wgrad_desc (include/psg_hip.h)."""
+    _fields_ = [
+        ("dtype", C.c_int32), ("B", C.c_int32), ("Hi", C.c_int32), ("Wi", C.c_int32), ("Cin", C.c_int32),
+        ("Ho", C.c_int32), ("Wo", C.c_int32), ("Cout", C.c_int32),
+        ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("accumulate", C.c_int32),
+        ("ldx", C.c_int64), ("lddy", C.c_int64),
+        ("x", c_void_p), ("dy", c_void_p), ("dw", c_void_p), ("ws", c_void_p), ("ws_bytes", C.c_int64),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/psg_hip.h declares
+SIGNATURES = {
+    "psg_last_error": (C.c_char_p, []),
+    "psg_version": (c_int, []),
+    "psg_init": (c_int, [c_int]),
+    "psg_noise_add_f32": (c_int, [c_void_p] * 7 + [c_int64, c_int64, c_int, c_int, c_void_p]),
+    "psg_noise_fallback_f32": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_void_p]),
+    "psg_ddpm_update_f32": (c_int, [c_void_p] * 7 + [c_int64, c_void_p]),
+    "psg_smooth_l1_f32": (c_int, [c_void_p] * 5 + [c_float, c_float, c_int64, c_void_p, c_void_p]),
+    "psg_reduce_workspace_bytes": (c_int64, []),
+    "psg_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),
+    "psg_nhwc_to_nchw": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "psg_text_pool": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "psg_timestep_sinusoid": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
+    "psg_upsample_bilinear_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64] + [c_int] * 7 + [c_void_p]),
+    "psg_upsample_bilinear_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64] + [c_int] * 7 + [c_void_p]),
+    "psg_add": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
+    "psg_groupnorm_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 4 + [c_float, c_int, c_int, c_void_p]),
+    "psg_groupnorm_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64] + [c_void_p] * 4 + [c_void_p, c_int64, c_void_p, c_void_p]
+                          + [c_int] * 7 + [c_void_p, c_void_p]),
+    "psg_groupnorm_bwd_workspace_bytes": (c_int64, [c_int, c_int]),
+    "psg_conv_fwd": (c_int, [C.POINTER(ConvDesc), c_void_p]),
+    "psg_conv_wgrad": (c_int, [C.POINTER(WgradDesc), c_void_p]),
+    "psg_conv_wgrad_workspace_bytes": (c_int64, [C.POINTER(WgradDesc)]),
+    "psg_prep_weight": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "psg_kpad": (c_int64, [c_int64, c_int]),
+    "psg_colsum": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
+    "psg_colsum_workspace_bytes": (c_int64, [c_int64, c_int, c_int]),
+    "psg_epilogue_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_float, c_float,
+                                 c_uint64, c_int, c_void_p]),
+    "psg_dropout_apply": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_float, c_uint64, c_float, c_int, c_void_p]),
+    "psg_attn_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]
+                     + [c_int] * 5 + [c_float, c_float, c_uint64, c_int, c_void_p]),
+    "psg_attn_bwd": (c_int, [c_void_p, c_int64] * 5 + [c_void_p, c_void_p] + [c_void_p, c_int64] * 3
+                     + [c_int] * 5 + [c_float, c_float, c_uint64, c_int, c_void_p]),
+    "psg_sumsq_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
+    "psg_adamw_f32": (c_int, [c_void_p] * 4 + [c_int64] + [c_float] * 5 + [c_int, c_void_p, c_float, c_void_p, c_void_p]),
+    "psg_clip_scale_f32": (c_int, [c_void_p, c_int64, c_void_p, c_float, c_void_p]),
+}
+
+_lib = None
+_inited = set()
+
+
+class PsgError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen libpsg_hip.so and declare every entry point.  Raises if the library is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PsgError(
+            f"{LIB_PATH} not found: the HIP extension is not built. Run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C pokemon_sprite_generator_amd/csrc`). There is no CPU/eager fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)       # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().psg_last_error()
+        raise PsgError(f"{what} failed with code {rc}: {msg.decode() if msg else ''}")
+
+
+def init(device_index: int):
+    lib = load()
+    if device_index not in _inited:
+        check(lib.psg_init(int(device_index)), "psg_init")
+        _inited.add(device_index)
+    return lib
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dtype_code(dt):
+    if dt == torch.float32:
+        return PSG_F32
+    if dt == torch.bfloat16:
+        return PSG_BF16
+    raise PsgError(f"unsupported compute dtype {dt}")
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+# ---------------------------------------------------------------------------
+# grow-only device workspace (one per device; all kernels run on the current stream in order)
+# ---------------------------------------------------------------------------
+_ws = {}
+
+
+def workspace(nbytes: int, device):
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf

@@ -1,0 +1,326 @@
+// Implicit-GEMM convolution / linear on the gfx950 matrix cores.
+//
+//   acc[n, m] = sum_k W[n, k] * X[pix(m, k), ci(k)]        (MFMA A = weights, B = activations)
+//
+// The product is computed "swapped" (weights as the MFMA A operand) so that each
+// lane ends up holding 4 CONSECUTIVE OUTPUT CHANNELS of one pixel per accumulator
+// register group: the channels-last store is then an 8-byte (bf16) / 16-byte
+// (fp32) vector per lane and the fused epilogue (bias, per-sample add, activation,
+// dropout, gate, residual) reads its operands with the same vectors.
+//
+// Tiling: BM pixels x BN channels per 256-thread workgroup (4 waves, 2x2), K step
+// of 8 sixteen-byte chunks (64 bf16 / 32 fp32 values, always inside one filter
+// tap when Cin % chunk-run == 0).  Operand tiles are register-staged
+// (global_load_dwordx4 issued before the MFMA phase, ds_write_b128 after it) into
+// a double-buffered, XOR-swizzled LDS image (128-byte rows; chunk ^= (row>>1)&7
+// makes the ds_read_b128 fragment reads conflict-free), one barrier per K step.
+// bf16: v_mfma_f32_32x32x16_bf16; fp32: v_mfma_f32_32x32x2_f32 (exact fp32).
+// Workgroup ids are remapped XCD-aware (each XCD's L2 sees a contiguous range of
+// tiles) and rasterised in groups of 8 M-tiles sharing weight panels.
+#include "psg_common.h"
+
+namespace psg {
+
+struct ConvP {
+    const void* x; const void* w; void* y;
+    const float* bias; const void* rowadd; const void* residual; void* preact; const void* dact_u;
+    int64_t ldx, ldy, ldra, ldres, ldpre, lddact, ldw;
+    int B, Hi, Wi, Cin, Ho, Wo, N;
+    int ks, stride, pad, transposed;
+    int M, taps, cpt, KT, Kpad, fast, tpt;
+    int mtiles, ntiles;
+    int act; float alpha;
+    uint32_t drop_thresh; float drop_scale; uint64_t drop_seed;
+};
+
+template <typename T> struct Mma;
+template <> struct Mma<bf16_t> {
+    static __device__ __forceinline__ f32x16 run(const uint4& a, const uint4& b, f32x16 c) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a),
+                                                       *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
+    }
+};
+template <> struct Mma<float> {
+    static __device__ __forceinline__ f32x16 run(const uint4& a, const uint4& b, f32x16 c) {
+        const float* fa = reinterpret_cast<const float*>(&a);
+        const float* fb = reinterpret_cast<const float*>(&b);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[e], fb[e], c, 0, 0, 0);
+        return c;
+    }
+};
+
+__device__ __forceinline__ int lds_off(int row, int chunk) {   // byte offset inside a tile of 128-byte rows
+    return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
+}
+
+template <typename T, int BM, int BN>
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
+    constexpr int CH = Elem<T>::CH;
+    constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA tiles per wave along m / n
+    constexpr int JX = BM / 32, JW = BN / 32;   // staging passes (32 rows per pass)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // [buf][W tile BN rows | X tile BM rows], 128 B per row
+    constexpr int BUF_BYTES = (BM + BN) * 128;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave & 1, wm = wave >> 1;
+
+    // ---- XCD-aware tile id + grouped raster -------------------------------
+    int mt, nt;
+    {
+        const int nb = gridDim.x, bid = blockIdx.x;
+        const int q = nb >> 3, r = nb & 7, xcd = bid & 7;
+        const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        constexpr int GM = 8;
+        const int per_group = GM * p.ntiles;
+        const int g = lid / per_group, rem = lid - g * per_group;
+        const int gm = min(GM, p.mtiles - g * GM);
+        nt = rem / gm;
+        mt = g * GM + (rem - nt * gm);
+    }
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // ---- per-thread staging coordinates ------------------------------------
+    const int sc = tid & 7;          // chunk column within the K step
+    const int sr = tid >> 3;         // row within a 32-row pass
+    const T* xg = reinterpret_cast<const T*>(p.x);
+    const T* wg = reinterpret_cast<const T*>(p.w);
+
+    int64_t w_off[JW];               // element offset of the row start, or -1
+#pragma unroll
+    for (int j = 0; j < JW; ++j) {
+        const int n = n0 + sr + 32 * j;
+        w_off[j] = n < p.N ? (int64_t)n * p.ldw : -1;
+    }
+    int x_hb[JX], x_wb[JX], x_pb[JX];
+    {
+        const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+        for (int j = 0; j < JX; ++j) {
+            const int m = m0 + sr + 32 * j;
+            if (m < p.M) {
+                const int b = m / HoWo, rm = m - b * HoWo;
+                const int ho = rm / p.Wo, wo = rm - ho * p.Wo;
+                if (p.transposed) { x_hb[j] = ho + p.pad; x_wb[j] = wo + p.pad; }
+                else { x_hb[j] = ho * p.stride - p.pad; x_wb[j] = wo * p.stride - p.pad; }
+                x_pb[j] = b * p.Hi * p.Wi;
+            } else { x_hb[j] = -100000; x_wb[j] = -100000; x_pb[j] = 0; }
+        }
+    }
+
+    uint4 gw[JW], gx[JX];
+    auto load_tiles = [&](int kt) {
+        // weights: always in-bounds along K (Kpad), rows masked by N
+#pragma unroll
+        for (int j = 0; j < JW; ++j) {
+            if (w_off[j] >= 0) gw[j] = *reinterpret_cast<const uint4*>(wg + w_off[j] + (int64_t)(kt * 8 + sc) * CH);
+            else gw[j] = make_uint4(0, 0, 0, 0);
+        }
+        // activations: tap / channel decode (uniform on the fast path)
+        int tap, cc;
+        if (p.fast) { tap = kt / p.tpt; cc = (kt - tap * p.tpt) * 8 + sc; }
+        else { const int qi = kt * 8 + sc; tap = qi / p.cpt; cc = qi - tap * p.cpt; }
+        const bool tap_ok = tap < p.taps;
+        const int kh = tap / p.ks, kw = tap - kh * p.ks;
+#pragma unroll
+        for (int j = 0; j < JX; ++j) {
+            int sh, sw; bool ok = tap_ok;
+            if (p.transposed) {
+                const int th = x_hb[j] - kh, tw = x_wb[j] - kw;
+                if (p.stride == 1) { sh = th; sw = tw; }
+                else { sh = th >> 1; sw = tw >> 1; ok = ok && ((th | tw) & 1) == 0; }
+                ok = ok && th >= 0 && tw >= 0 && sh < p.Hi && sw < p.Wi;
+            } else {
+                sh = x_hb[j] + kh; sw = x_wb[j] + kw;
+                ok = ok && sh >= 0 && sw >= 0 && sh < p.Hi && sw < p.Wi;
+            }
+            if (ok) gx[j] = *reinterpret_cast<const uint4*>(xg + (int64_t)(x_pb[j] + sh * p.Wi + sw) * p.ldx + cc * CH);
+            else gx[j] = make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        char* base = smem + buf * BUF_BYTES;
+#pragma unroll
+        for (int j = 0; j < JW; ++j) *reinterpret_cast<uint4*>(base + lds_off(sr + 32 * j, sc)) = gw[j];
+#pragma unroll
+        for (int j = 0; j < JX; ++j) *reinterpret_cast<uint4*>(base + BN * 128 + lds_off(sr + 32 * j, sc)) = gx[j];
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    const int fr = lane & 31, fh = lane >> 5;
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < p.KT; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < p.KT) load_tiles(kt + 1);          // in flight during the MFMA phase
+        const char* wb = smem + buf * BUF_BYTES;
+        const char* xb = wb + BN * 128;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const int c = 2 * s + fh;
+            uint4 wf[TN], xf[TM];
+#pragma unroll
+            for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const uint4*>(wb + lds_off(wn * (TN * 32) + i * 32 + fr, c));
+#pragma unroll
+            for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const uint4*>(xb + lds_off(wm * (TM * 32) + j * 32 + fr, c));
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) acc[i][j] = Mma<T>::run(wf[i], xf[j], acc[i][j]);
+        }
+        if (kt + 1 < p.KT) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- fused epilogue ------------------------------------------------------
+    T* yg = reinterpret_cast<T*>(p.y);
+    const T* rag = reinterpret_cast<const T*>(p.rowadd);
+    const T* resg = reinterpret_cast<const T*>(p.residual);
+    T* preg = reinterpret_cast<T*>(p.preact);
+    const T* dug = reinterpret_cast<const T*>(p.dact_u);
+    const int HoWo = p.Ho * p.Wo;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = m0 + wm * (TM * 32) + j * 32 + fr;
+        if (m >= p.M) continue;
+        const int b = m / HoWo;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * (TN * 32) + i * 32 + 8 * g + 4 * fh;
+                if (n >= p.N) continue;
+                f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+                if (rag) v += load4<T>(rag + (int64_t)b * p.ldra + n);
+                if (preg) store4<T>(preg + (int64_t)m * p.ldpre + n, v);
+                if (dug) {          // backward form: multiply by act'(u) of the saved pre-activation
+                    const f32x4 u = load4<T>(dug + (int64_t)m * p.lddact + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] *= act_grad(u[e], p.act);
+                } else if (p.act != PSG_ACT_NONE) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = act_f(v[e], p.act);
+                }
+                if (p.drop_thresh) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        v[e] = drop_keep(p.drop_seed, (uint64_t)m * p.N + n + e, p.drop_thresh) ? v[e] * p.drop_scale : 0.f;
+                }
+                v *= p.alpha;
+                if (resg) v += load4<T>(resg + (int64_t)m * p.ldres + n);
+                store4<T>(yg + (int64_t)m * p.ldy + n, v);
+            }
+        }
+    }
+}
+
+template <typename T, int BM, int BN>
+static int launch_conv(const ConvP& p, hipStream_t stream) {
+    const size_t lds = 2 * (size_t)(BM + BN) * 128;
+    ConvP q = p;
+    q.mtiles = (p.M + BM - 1) / BM;
+    q.ntiles = (p.N + BN - 1) / BN;
+    const int grid = q.mtiles * q.ntiles;
+    hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN>), dim3(grid), dim3(256), lds, stream, q);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "conv_gemm launch");
+    return PSG_OK;
+}
+
+}  // namespace psg
+using namespace psg;
+
+extern "C" {
+
+int psg_conv_init_attrs(void) {
+#define SET_LDS(K, BYTES) PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES))
+    SET_LDS((conv_gemm_kernel<float, 128, 128>), 2 * 256 * 128);
+    SET_LDS((conv_gemm_kernel<bf16_t, 128, 128>), 2 * 256 * 128);
+    SET_LDS((conv_gemm_kernel<float, 128, 64>), 2 * 192 * 128);
+    SET_LDS((conv_gemm_kernel<bf16_t, 128, 64>), 2 * 192 * 128);
+    SET_LDS((conv_gemm_kernel<float, 64, 64>), 2 * 128 * 128);
+    SET_LDS((conv_gemm_kernel<bf16_t, 64, 64>), 2 * 128 * 128);
+#undef SET_LDS
+    return PSG_OK;
+}
+
+int psg_conv_fwd(const psg_conv_desc* d, psg_stream_t stream) {
+    PSG_REQUIRE(d && d->x && d->w && d->y, PSG_ERR_ARG, "conv_fwd: null pointer");
+    PSG_REQUIRE(d->dtype == PSG_F32 || d->dtype == PSG_BF16, PSG_ERR_DTYPE, "conv_fwd: dtype %d", d->dtype);
+    const int CH = d->dtype == PSG_BF16 ? 8 : 4;
+    PSG_REQUIRE(d->B > 0 && d->Hi > 0 && d->Wi > 0 && d->Cin > 0 && d->Ho > 0 && d->Wo > 0 && d->Cout > 0, PSG_ERR_SHAPE,
+                "conv_fwd: non-positive dimension");
+    PSG_REQUIRE((d->ksize == 1 && d->pad == 0) || (d->ksize == 3 && d->pad == 1), PSG_ERR_SHAPE, "conv_fwd: ksize/pad %d/%d", d->ksize, d->pad);
+    PSG_REQUIRE(d->stride == 1 || d->stride == 2, PSG_ERR_SHAPE, "conv_fwd: stride %d", d->stride);
+    PSG_REQUIRE(d->Cin % CH == 0, PSG_ERR_SHAPE, "conv_fwd: Cin=%d must be a multiple of %d", d->Cin, CH);
+    PSG_REQUIRE(d->Cout % 4 == 0, PSG_ERR_SHAPE, "conv_fwd: Cout=%d must be a multiple of 4", d->Cout);
+    PSG_REQUIRE(d->ldx >= d->Cin && d->ldx % CH == 0, PSG_ERR_SHAPE, "conv_fwd: ldx=%ld (Cin=%d)", (long)d->ldx, d->Cin);
+    PSG_REQUIRE(d->ldy >= d->Cout && d->ldy % 4 == 0, PSG_ERR_SHAPE, "conv_fwd: ldy=%ld", (long)d->ldy);
+    PSG_REQUIRE(aligned16(d->x) && aligned16(d->w) && aligned16(d->y), PSG_ERR_ALIGN, "conv_fwd: x/w/y must be 16-byte aligned");
+    PSG_REQUIRE(!d->bias || aligned16(d->bias), PSG_ERR_ALIGN, "conv_fwd: bias alignment");
+    PSG_REQUIRE(!d->rowadd || (aligned16(d->rowadd) && d->ld_rowadd % 4 == 0), PSG_ERR_ALIGN, "conv_fwd: rowadd alignment");
+    PSG_REQUIRE(!d->residual || (aligned16(d->residual) && d->ld_residual % 4 == 0), PSG_ERR_ALIGN, "conv_fwd: residual alignment");
+    PSG_REQUIRE(!d->preact || (aligned16(d->preact) && d->ld_preact % 4 == 0), PSG_ERR_ALIGN, "conv_fwd: preact alignment");
+    PSG_REQUIRE(!d->dact_u || (aligned16(d->dact_u) && d->ld_dact % 4 == 0), PSG_ERR_ALIGN, "conv_fwd: dact_u alignment");
+    PSG_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, PSG_ERR_ARG, "conv_fwd: drop_p %f", d->drop_p);
+    // geometry consistency
+    if (!d->transposed) {
+        PSG_REQUIRE(d->Ho == (d->Hi + 2 * d->pad - d->ksize) / d->stride + 1 && d->Wo == (d->Wi + 2 * d->pad - d->ksize) / d->stride + 1,
+                    PSG_ERR_SHAPE, "conv_fwd: output %dx%d inconsistent with input %dx%d k%d s%d p%d", d->Ho, d->Wo, d->Hi, d->Wi, d->ksize, d->stride, d->pad);
+    } else {
+        PSG_REQUIRE(d->Hi == (d->Ho + 2 * d->pad - d->ksize) / d->stride + 1 && d->Wi == (d->Wo + 2 * d->pad - d->ksize) / d->stride + 1,
+                    PSG_ERR_SHAPE, "conv_fwd(transposed): grad grid %dx%d inconsistent with input grid %dx%d", d->Hi, d->Wi, d->Ho, d->Wo);
+    }
+    const int64_t M = (int64_t)d->B * d->Ho * d->Wo;
+    PSG_REQUIRE(M < (1ll << 30) && (int64_t)d->B * d->Hi * d->Wi < (1ll << 30), PSG_ERR_SHAPE, "conv_fwd: too many pixels");
+    const int taps = d->ksize * d->ksize;
+    const int64_t Kpad = psg_kpad((int64_t)taps * d->Cin, d->dtype);
+    PSG_REQUIRE(d->ldw == 0 || (d->ldw >= Kpad && d->ldw % CH == 0), PSG_ERR_SHAPE, "conv_fwd: ldw=%ld < Kpad=%ld", (long)d->ldw, (long)Kpad);
+
+    ConvP p;
+    p.x = d->x; p.w = d->w; p.y = d->y; p.bias = d->bias; p.rowadd = d->rowadd; p.residual = d->residual;
+    p.preact = d->preact; p.dact_u = d->dact_u;
+    p.ldw = d->ldw > 0 ? d->ldw : Kpad;
+    p.ldx = d->ldx; p.ldy = d->ldy; p.ldra = d->ld_rowadd; p.ldres = d->ld_residual; p.ldpre = d->ld_preact; p.lddact = d->ld_dact;
+    p.B = d->B; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.N = d->Cout;
+    p.ks = d->ksize; p.stride = d->stride; p.pad = d->pad; p.transposed = d->transposed;
+    p.M = (int)M; p.taps = taps; p.cpt = d->Cin / CH; p.Kpad = (int)Kpad; p.KT = (int)(Kpad / (8 * CH));
+    p.fast = (p.cpt % 8 == 0) ? 1 : 0; p.tpt = p.fast ? p.cpt / 8 : 1;
+    p.act = d->act; p.alpha = d->alpha;
+    p.drop_thresh = d->drop_p > 0.f ? drop_thresh(d->drop_p) : 0u;
+    p.drop_scale = d->drop_p > 0.f ? 1.0f / (1.0f - d->drop_p) : 1.0f;
+    p.drop_seed = d->drop_seed;
+    p.mtiles = p.ntiles = 0;
+
+    // tile choice: keep >= ~2 waves of workgroups on the chip when the problem allows
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t t128 = ((M + 127) / 128) * ((d->Cout + 127) / 128);
+    const int64_t t12864 = ((M + 127) / 128) * ((d->Cout + 63) / 64);
+    const bool n_waste_128 = (d->Cout % 128) != 0 && (d->Cout % 128) <= 64;   // e.g. 320 -> last tile half empty
+    int BM = 128, BN = 128;
+    if (d->Cout <= 64 || (n_waste_128 && t12864 >= 512) || t128 < 512) { BM = 128; BN = 64; }
+    if (t12864 < 512 && BN == 64) { BM = 64; BN = 64; }
+    if (d->dtype == PSG_F32) {
+        if (BM == 128 && BN == 128) return launch_conv<float, 128, 128>(p, s);
+        if (BM == 128 && BN == 64) return launch_conv<float, 128, 64>(p, s);
+        return launch_conv<float, 64, 64>(p, s);
+    } else {
+        if (BM == 128 && BN == 128) return launch_conv<bf16_t, 128, 128>(p, s);
+        if (BM == 128 && BN == 64) return launch_conv<bf16_t, 128, 64>(p, s);
+        return launch_conv<bf16_t, 64, 64>(p, s);
+    }
+}
+
+}  // extern "C"

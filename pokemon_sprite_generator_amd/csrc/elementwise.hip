@@ -1,0 +1,696 @@
+// HBM-bound elementwise / reduction kernels of the U-Net train step (gfx950).
+// Every kernel is a single streaming pass; roofline = HBM bandwidth.
+#include "psg_common.h"
+
+namespace psg {
+
+static thread_local char g_err[512] = "";
+
+int set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+int hip_fail(hipError_t e, const char* what) {
+    snprintf(g_err, sizeof(g_err), "HIP error %d (%s) at %s", (int)e, hipGetErrorString(e), what);
+    (void)hipGetLastError();
+    return PSG_ERR_HIP;
+}
+
+static inline int grid_for(int64_t n, int block, int max_blocks = 2048) {
+    int64_t g = (n + block - 1) / block;
+    if (g > max_blocks) g = max_blocks;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+// ---------------------------------------------------------------------------
+// add_noise: bit-exact (two rounded multiplies, one rounded add; no FMA contraction)
+// ---------------------------------------------------------------------------
+__global__ void noise_add_kernel(const float* __restrict__ x0, const float* __restrict__ noise,
+                                 const int64_t* __restrict__ t, const float* __restrict__ tabA,
+                                 const float* __restrict__ tabB, float* __restrict__ out,
+                                 int32_t* flag, int64_t B, int64_t chw, int num_t, int do_clamp) {
+    const int64_t n = B * chw;
+    int bad = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / chw;
+        int64_t tb = t[b];
+        if (tb < 0 || tb >= num_t) { bad |= 2; tb = tb < 0 ? 0 : num_t - 1; }
+        const float a = tabA[tb], c = tabB[tb];
+        float x = x0[i];
+        if (do_clamp) x = fminf(fmaxf(x, -3.0f), 3.0f);
+        const float r = __fadd_rn(__fmul_rn(a, x), __fmul_rn(c, noise[i]));
+        out[i] = r;
+        if (isnan(r) || isinf(r)) bad |= 1;
+    }
+    if (bad) atomicOr(flag, bad);
+}
+
+__global__ void noise_fallback_kernel(const float* __restrict__ x0, const float* __restrict__ noise,
+                                      float* __restrict__ out, const int32_t* flag, int64_t n, int do_clamp) {
+    if (((*flag) & 1) == 0) return;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float x = x0[i];
+        if (do_clamp) x = fminf(fmaxf(x, -3.0f), 3.0f);
+        out[i] = __fadd_rn(x, __fmul_rn(0.1f, noise[i]));
+    }
+}
+
+__global__ void ddpm_update_kernel(float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ z,
+                                   const float* __restrict__ c1t, const float* __restrict__ c2t,
+                                   const float* __restrict__ sgt, const int32_t* t_dev, int64_t n) {
+    const int t = *t_dev;
+    const float c1 = c1t[t], c2 = c2t[t], sg = sgt[t];
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float r = __fmul_rn(c1, __fsub_rn(x[i], __fmul_rn(c2, eps[i])));
+        if (t > 0) r = __fadd_rn(r, __fmul_rn(sg, z[i]));
+        x[i] = r;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// deterministic two-stage reductions (fixed grid, fixed order)
+// ---------------------------------------------------------------------------
+constexpr int RED_BLOCKS = 1024;
+constexpr int RED_THREADS = 256;
+
+__global__ void smooth_l1_kernel(const float* __restrict__ pred, const float* __restrict__ target,
+                                 float* __restrict__ grad, float* __restrict__ partial, int32_t* nan_flag,
+                                 float beta, float grad_scale, int64_t n) {
+    __shared__ float red[16];
+    float acc = 0.f;
+    int bad = 0;
+    const float inv_n = 1.0f / (float)n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float p = pred[i];
+        const float d = p - target[i];
+        const float ad = fabsf(d);
+        float g;
+        if (ad < beta) { acc += 0.5f * d * d / beta; g = d / beta; }
+        else { acc += ad - 0.5f * beta; g = d > 0.f ? 1.f : -1.f; }
+        if (isnan(p) || isinf(p)) bad = 1;
+        if (grad) grad[i] = g * inv_n * grad_scale;
+    }
+    const float s = block_sum(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+    if (bad && nan_flag) atomicOr(nan_flag, 4);
+}
+
+__global__ void sumsq_kernel(const float* __restrict__ g, float* __restrict__ partial, int64_t n) {
+    __shared__ float red[16];
+    float acc = 0.f;
+    const int64_t n4 = n >> 2;
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 v = g4[i];
+        acc += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { float v = g[(n4 << 2) + threadIdx.x]; acc += v * v; }
+    const float s = block_sum(acc, red);
+    if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+
+// final stage: one block sums `count` partials in a fixed order; out = scale*sum (+ out if accumulate)
+__global__ void finish_sum_kernel(const float* __restrict__ partial, int count, float* out, float scale,
+                                  int accumulate, int32_t* nan_flag) {
+    __shared__ float red[16];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < count; i += blockDim.x) acc += partial[i];
+    const float s = block_sum(acc, red);
+    if (threadIdx.x == 0) {
+        float r = s * scale;
+        if (accumulate) r += *out;
+        *out = r;
+        if (nan_flag && (isnan(r) || isinf(r))) atomicOr(nan_flag, 8);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// layout conversions at the NCHW fp32 boundary (tiny: 8 channels)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int64_t ld, int B, int C, int HW) {
+    const int64_t n = (int64_t)B * C * HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t r = i / C;           // b*HW + p
+        const int p = (int)(r % HW);
+        const int64_t b = r / HW;
+        Elem<T>::st(dst + r * ld + c, src[(b * C + c) * HW + p]);
+    }
+}
+template <typename T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, int64_t ld, float* __restrict__ dst, int B, int C, int HW) {
+    const int64_t n = (int64_t)B * C * HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int p = (int)(i % HW);
+        const int64_t r = i / HW;          // b*C + c
+        const int c = (int)(r % C);
+        const int64_t b = r / C;
+        dst[i] = Elem<T>::ld(src + (b * HW + p) * ld + c);
+    }
+}
+
+template <typename T>
+__global__ void text_pool_kernel(const float* __restrict__ text, T* __restrict__ pooled, int64_t ldp,
+                                 T* __restrict__ cast, int B, int S, int D) {
+    const int b = blockIdx.x;
+    for (int dcol = threadIdx.x; dcol < D; dcol += blockDim.x) {
+        float acc = 0.f;
+        for (int s = 0; s < S; ++s) {
+            const float v = text[((int64_t)b * S + s) * D + dcol];
+            acc += v;
+            if (cast) Elem<T>::st(cast + ((int64_t)b * S + s) * D + dcol, v);
+        }
+        Elem<T>::st(pooled + (int64_t)b * ldp + dcol, acc / (float)S);
+    }
+}
+
+template <typename T>
+__global__ void sinusoid_kernel(const int64_t* __restrict__ t, const float* __restrict__ coeff, T* __restrict__ out,
+                                int64_t ld, int B, int half) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * half) return;
+    const int b = i / half, j = i % half;
+    const float e = __fmul_rn((float)t[b], coeff[j]);   // t.float() * coeff, unet.py:47-49
+    Elem<T>::st(out + (int64_t)b * ld + j, sinf(e));
+    Elem<T>::st(out + (int64_t)b * ld + half + j, cosf(e));
+}
+
+// bilinear, align_corners=False: src = (dst + 0.5) * (in/out) - 0.5, clamped at 0 (PyTorch area_pixel_compute_source_index)
+__device__ __forceinline__ void bilin_coord(int o, int in, int out, int& i0, int& i1, float& w1) {
+    const float scale = (float)in / (float)out;
+    float s = ((float)o + 0.5f) * scale - 0.5f;
+    if (s < 0.f) s = 0.f;
+    i0 = (int)s;
+    if (i0 > in - 1) i0 = in - 1;
+    i1 = i0 + (i0 < in - 1 ? 1 : 0);
+    w1 = s - (float)i0;
+}
+
+template <typename T>
+__global__ void upsample_fwd_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy,
+                                    int B, int Hi, int Wi, int Ho, int Wo, int C) {
+    const int c4n = C >> 2;
+    const int64_t n = (int64_t)B * Ho * Wo * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        int64_t r = i / c4n;
+        const int wo = (int)(r % Wo); r /= Wo;
+        const int ho = (int)(r % Ho);
+        const int64_t b = r / Ho;
+        int h0, h1, w0, w1; float lh, lw;
+        bilin_coord(ho, Hi, Ho, h0, h1, lh);
+        bilin_coord(wo, Wi, Wo, w0, w1, lw);
+        const T* base = x + (b * Hi * Wi) * ldx + c;
+        f32x4 v00 = load4<T>(base + ((int64_t)h0 * Wi + w0) * ldx);
+        f32x4 v01 = load4<T>(base + ((int64_t)h0 * Wi + w1) * ldx);
+        f32x4 v10 = load4<T>(base + ((int64_t)h1 * Wi + w0) * ldx);
+        f32x4 v11 = load4<T>(base + ((int64_t)h1 * Wi + w1) * ldx);
+        const float a00 = (1.f - lh) * (1.f - lw), a01 = (1.f - lh) * lw, a10 = lh * (1.f - lw), a11 = lh * lw;
+        f32x4 o = v00 * a00 + v01 * a01 + v10 * a10 + v11 * a11;
+        store4<T>(y + ((b * Ho + ho) * Wo + wo) * ldy + c, o);
+    }
+}
+
+// gather-form backward: dx[hi,wi] = sum over the (few) output pixels whose stencil touches it; deterministic
+template <typename T>
+__global__ void upsample_bwd_kernel(const T* __restrict__ dy, int64_t lddy, T* __restrict__ dx, int64_t lddx,
+                                    int B, int Hi, int Wi, int Ho, int Wo, int C) {
+    const int c4n = C >> 2;
+    const int64_t n = (int64_t)B * Hi * Wi * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        int64_t r = i / c4n;
+        const int wi = (int)(r % Wi); r /= Wi;
+        const int hi = (int)(r % Hi);
+        const int64_t b = r / Hi;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // output rows that can touch hi: scale = Hi/Ho <= 1 -> ho in a small window
+        const int ho_lo = max(0, (int)floorf(((float)hi - 1.0f + 0.5f) * (float)Ho / (float)Hi - 0.5f) - 1);
+        const int ho_hi = min(Ho - 1, (int)ceilf(((float)hi + 1.0f + 0.5f) * (float)Ho / (float)Hi - 0.5f) + 1);
+        const int wo_lo = max(0, (int)floorf(((float)wi - 1.0f + 0.5f) * (float)Wo / (float)Wi - 0.5f) - 1);
+        const int wo_hi = min(Wo - 1, (int)ceilf(((float)wi + 1.0f + 0.5f) * (float)Wo / (float)Wi - 0.5f) + 1);
+        for (int ho = ho_lo; ho <= ho_hi; ++ho) {
+            int h0, h1; float lh;
+            bilin_coord(ho, Hi, Ho, h0, h1, lh);
+            float wh = 0.f;
+            if (h0 == hi) wh += 1.f - lh;
+            if (h1 == hi) wh += lh;
+            if (wh == 0.f) continue;
+            for (int wo = wo_lo; wo <= wo_hi; ++wo) {
+                int w0, w1; float lw;
+                bilin_coord(wo, Wi, Wo, w0, w1, lw);
+                float ww = 0.f;
+                if (w0 == wi) ww += 1.f - lw;
+                if (w1 == wi) ww += lw;
+                if (ww == 0.f) continue;
+                f32x4 g = load4<T>(dy + ((b * Ho + ho) * Wo + wo) * lddy + c);
+                acc += g * (wh * ww);
+            }
+        }
+        store4<T>(dx + ((b * Hi + hi) * Wi + wi) * lddx + c, acc);
+    }
+}
+
+template <typename T>
+__global__ void add_kernel(const T* __restrict__ a, int64_t lda, const T* __restrict__ b, int64_t ldb,
+                           T* __restrict__ y, int64_t ldy, int64_t rows, int cols) {
+    const int c4n = cols >> 2;
+    const int64_t n = rows * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        const int64_t r = i / c4n;
+        store4<T>(y + r * ldy + c, load4<T>(a + r * lda + c) + load4<T>(b + r * ldb + c));
+    }
+}
+
+template <typename T>
+__global__ void dropout_apply_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy,
+                                     int64_t rows, int cols, uint32_t thresh, uint64_t seed, float scale) {
+    const int c4n = cols >> 2;
+    const int64_t n = rows * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        const int64_t r = i / c4n;
+        f32x4 v = load4<T>(x + r * ldx + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = drop_keep(seed, (uint64_t)r * cols + c + e, thresh) ? v[e] * scale : 0.f;
+        store4<T>(y + r * ldy + c, v);
+    }
+}
+
+template <typename T>
+__global__ void epilogue_bwd_kernel(const T* __restrict__ dy, int64_t lddy, const T* __restrict__ u, int64_t ldu,
+                                    T* __restrict__ g, int64_t ldg, int64_t rows, int cols, int act, float alpha,
+                                    uint32_t thresh, float drop_scale, uint64_t seed) {
+    const int c4n = cols >> 2;
+    const int64_t n = rows * c4n;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % c4n) * 4;
+        const int64_t r = i / c4n;
+        f32x4 v = load4<T>(dy + r * lddy + c) * alpha;
+        if (thresh) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = drop_keep(seed, (uint64_t)r * cols + c + e, thresh) ? v[e] * drop_scale : 0.f;
+        }
+        if (act != PSG_ACT_NONE) {
+            const f32x4 uu = load4<T>(u + r * ldu + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] *= act_grad(uu[e], act);
+        }
+        store4<T>(g + r * ldg + c, v);
+    }
+}
+
+// ---------------------------------------------------------------------------
+// optimizer
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float clip_coef_dev(const float* normsq, float max_norm) {
+    if (!normsq) return 1.0f;
+    const float nrm = sqrtf(*normsq);
+    const float c = max_norm / (nrm + 1e-6f);
+    return c < 1.0f ? c : 1.0f;
+}
+
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, int64_t n, float lr, float beta1, float beta2, float eps,
+                             float wd, float bc1, float bc2_sqrt, const float* normsq, float max_norm,
+                             const int32_t* skip_flag) {
+    if (skip_flag && *skip_flag) return;
+    const float coef = clip_coef_dev(normsq, max_norm);
+    const float step_size = lr / bc1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float gi = g[i] * coef;
+        float pi = p[i] * (1.0f - lr * wd);
+        const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        pi -= step_size * (mi / denom);
+        p[i] = pi; m[i] = mi; v[i] = vi;
+    }
+}
+
+__global__ void clip_scale_kernel(float* __restrict__ g, int64_t n, const float* normsq, float max_norm) {
+    const float coef = clip_coef_dev(normsq, max_norm);
+    if (coef >= 1.0f) return;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) g[i] *= coef;
+}
+
+// ---------------------------------------------------------------------------
+// weight preparation: fp32 OIHW -> [O][Kpad] (kh,kw,ci) and [I][Kpad'] (kh,kw,co)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void prep_weight_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd,
+                                   int O, int I, int taps, int64_t kpf, int64_t kpd) {
+    if (wf) {
+        const int64_t n = (int64_t)O * kpf;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t k = i % kpf;
+            const int64_t o = i / kpf;
+            float v = 0.f;
+            if (k < (int64_t)taps * I) {
+                const int tap = (int)(k / I), ci = (int)(k % I);
+                v = w[(o * I + ci) * taps + tap];
+            }
+            Elem<T>::st(wf + i, v);
+        }
+    }
+    if (wd) {
+        const int64_t n = (int64_t)I * kpd;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t k = i % kpd;
+            const int64_t ci = i / kpd;
+            float v = 0.f;
+            if (k < (int64_t)taps * O) {
+                const int tap = (int)(k / O), co = (int)(k % O);
+                v = w[((int64_t)co * I + ci) * taps + tap];
+            }
+            Elem<T>::st(wd + i, v);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// column sums (bias gradient / per-sample rowadd gradient), deterministic 2-stage
+// grid: (col blocks of 64*4 columns... see launcher)
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void colsum_stage1(const T* __restrict__ a, int64_t lda, float* __restrict__ partial,
+                              int64_t R, int groups, int cols, int splits, int64_t rows_per_split) {
+    // blockIdx.x: column block (blockDim.x columns... each thread 1 column), blockIdx.y: group*splits + split
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int gs = blockIdx.y;
+    const int g = gs / splits, s = gs % splits;
+    if (c >= cols) return;
+    const int64_t r0 = (int64_t)s * rows_per_split;
+    int64_t r1 = r0 + rows_per_split;
+    if (r1 > R) r1 = R;
+    float acc = 0.f;
+    const T* base = a + ((int64_t)g * R) * lda + c;
+    for (int64_t r = r0; r < r1; ++r) acc += Elem<T>::ld(base + r * lda);
+    partial[(int64_t)gs * cols + c] = acc;
+}
+template <typename TO>
+__global__ void colsum_stage2(const float* __restrict__ partial, TO* __restrict__ out, int64_t ld_out,
+                              int groups, int cols, int splits, int accumulate) {
+    const int64_t n = (int64_t)groups * cols;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cols);
+        const int64_t g = i / cols;
+        float acc = 0.f;
+        for (int s = 0; s < splits; ++s) acc += partial[((int64_t)g * splits + s) * cols + c];
+        TO* o = out + g * ld_out + c;
+        if (accumulate) acc += Elem<TO>::ld(o);
+        Elem<TO>::st(o, acc);
+    }
+}
+
+}  // namespace psg
+
+using namespace psg;
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+extern "C" {
+
+const char* psg_last_error(void) { return g_err; }
+int psg_version(void) { return 100; }
+
+int psg_conv_init_attrs(void);   // conv_gemm.hip
+int psg_wgrad_init_attrs(void);  // wgrad.hip
+int psg_attn_init_attrs(void);   // attention.hip
+int psg_gn_init_attrs(void);     // groupnorm.hip
+
+int psg_init(int device) {
+    PSG_HIP_CHECK(hipSetDevice(device));
+    int rc;
+    if ((rc = psg_conv_init_attrs()) != PSG_OK) return rc;
+    if ((rc = psg_wgrad_init_attrs()) != PSG_OK) return rc;
+    if ((rc = psg_attn_init_attrs()) != PSG_OK) return rc;
+    if ((rc = psg_gn_init_attrs()) != PSG_OK) return rc;
+    return PSG_OK;
+}
+
+int psg_noise_add_f32(const float* x0, const float* noise, const int64_t* t, const float* tabA,
+                      const float* tabB, float* out, int32_t* flag, int64_t B, int64_t chw, int num_t,
+                      int do_clamp, psg_stream_t stream) {
+    PSG_REQUIRE(x0 && noise && t && tabA && tabB && out && flag, PSG_ERR_ARG, "noise_add: null pointer");
+    PSG_REQUIRE(B >= 0 && chw > 0 && num_t > 0, PSG_ERR_SHAPE, "noise_add: bad shape B=%ld chw=%ld", (long)B, (long)chw);
+    if (B == 0) return PSG_OK;
+    hipLaunchKernelGGL(noise_add_kernel, dim3(grid_for(B * chw, 256)), dim3(256), 0, (hipStream_t)stream, x0, noise, t,
+                       tabA, tabB, out, flag, B, chw, num_t, do_clamp);
+    PSG_LAUNCH_CHECK("noise_add");
+    return PSG_OK;
+}
+
+int psg_noise_fallback_f32(const float* x0, const float* noise, float* out, const int32_t* flag, int64_t n,
+                           int do_clamp, psg_stream_t stream) {
+    PSG_REQUIRE(x0 && noise && out && flag, PSG_ERR_ARG, "noise_fallback: null pointer");
+    if (n <= 0) return PSG_OK;
+    hipLaunchKernelGGL(noise_fallback_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x0, noise, out,
+                       flag, n, do_clamp);
+    PSG_LAUNCH_CHECK("noise_fallback");
+    return PSG_OK;
+}
+
+int psg_ddpm_update_f32(float* x, const float* eps, const float* z, const float* c1, const float* c2,
+                        const float* sigma, const int32_t* t_dev, int64_t n, psg_stream_t stream) {
+    PSG_REQUIRE(x && eps && z && c1 && c2 && sigma && t_dev, PSG_ERR_ARG, "ddpm_update: null pointer");
+    if (n <= 0) return PSG_OK;
+    hipLaunchKernelGGL(ddpm_update_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, eps, z, c1, c2,
+                       sigma, t_dev, n);
+    PSG_LAUNCH_CHECK("ddpm_update");
+    return PSG_OK;
+}
+
+int64_t psg_reduce_workspace_bytes(void) { return (int64_t)RED_BLOCKS * sizeof(float); }
+
+int psg_smooth_l1_f32(const float* pred, const float* target, float* grad, float* loss_out, int32_t* nan_flag,
+                      float beta, float grad_scale, int64_t n, void* ws, psg_stream_t stream) {
+    PSG_REQUIRE(pred && target && loss_out && ws, PSG_ERR_ARG, "smooth_l1: null pointer");
+    PSG_REQUIRE(n > 0 && beta > 0.f, PSG_ERR_SHAPE, "smooth_l1: n=%ld beta=%f", (long)n, beta);
+    const int g = grid_for(n, RED_THREADS, RED_BLOCKS);
+    hipLaunchKernelGGL(smooth_l1_kernel, dim3(g), dim3(RED_THREADS), 0, (hipStream_t)stream, pred, target, grad,
+                       (float*)ws, nan_flag, beta, grad_scale, n);
+    PSG_LAUNCH_CHECK("smooth_l1");
+    hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)ws, g, loss_out,
+                       1.0f / (float)n, 0, nan_flag);
+    PSG_LAUNCH_CHECK("smooth_l1_finish");
+    return PSG_OK;
+}
+
+int psg_sumsq_f32(const float* g, int64_t n, float* out, int accumulate, void* ws, psg_stream_t stream) {
+    PSG_REQUIRE(g && out && ws, PSG_ERR_ARG, "sumsq: null pointer");
+    PSG_REQUIRE(n > 0, PSG_ERR_SHAPE, "sumsq: n=%ld", (long)n);
+    PSG_REQUIRE(aligned16(g), PSG_ERR_ALIGN, "sumsq: g must be 16-byte aligned");
+    const int gr = grid_for((n + 3) / 4, RED_THREADS, RED_BLOCKS);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(gr), dim3(RED_THREADS), 0, (hipStream_t)stream, g, (float*)ws, n);
+    PSG_LAUNCH_CHECK("sumsq");
+    hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, (const float*)ws, gr, out, 1.0f,
+                       accumulate, (int32_t*)nullptr);
+    PSG_LAUNCH_CHECK("sumsq_finish");
+    return PSG_OK;
+}
+
+int psg_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int step, const float* normsq, float max_norm,
+                  const int32_t* skip_flag, psg_stream_t stream) {
+    PSG_REQUIRE(p && g && m && v, PSG_ERR_ARG, "adamw: null pointer");
+    PSG_REQUIRE(n > 0 && step >= 1, PSG_ERR_SHAPE, "adamw: n=%ld step=%d", (long)n, step);
+    const float bc1 = 1.0f - powf(beta1, (float)step);
+    const float bc2 = 1.0f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr,
+                       beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), normsq, max_norm, skip_flag);
+    PSG_LAUNCH_CHECK("adamw");
+    return PSG_OK;
+}
+
+int psg_clip_scale_f32(float* g, int64_t n, const float* normsq, float max_norm, psg_stream_t stream) {
+    PSG_REQUIRE(g && normsq, PSG_ERR_ARG, "clip_scale: null pointer");
+    if (n <= 0) return PSG_OK;
+    hipLaunchKernelGGL(clip_scale_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, g, n, normsq,
+                       max_norm);
+    PSG_LAUNCH_CHECK("clip_scale");
+    return PSG_OK;
+}
+
+#define DISPATCH_DTYPE(dtype, CALL_F32, CALL_BF16)                                        \
+    if ((dtype) == PSG_F32) { CALL_F32; }                                                 \
+    else if ((dtype) == PSG_BF16) { CALL_BF16; }                                          \
+    else return set_error(PSG_ERR_DTYPE, "unsupported dtype %d", (int)(dtype));
+
+int psg_nchw_to_nhwc(const float* src, void* dst, int64_t ld_dst, int B, int C, int HW, int dtype, psg_stream_t stream) {
+    PSG_REQUIRE(src && dst, PSG_ERR_ARG, "nchw_to_nhwc: null pointer");
+    PSG_REQUIRE(B > 0 && C > 0 && HW > 0 && ld_dst >= C, PSG_ERR_SHAPE, "nchw_to_nhwc: bad shape");
+    const int g = grid_for((int64_t)B * C * HW, 256);
+    DISPATCH_DTYPE(dtype,
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, src, (float*)dst, ld_dst, B, C, HW),
+        hipLaunchKernelGGL(nchw_to_nhwc_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst, ld_dst, B, C, HW));
+    PSG_LAUNCH_CHECK("nchw_to_nhwc");
+    return PSG_OK;
+}
+
+int psg_nhwc_to_nchw(const void* src, int64_t ld_src, float* dst, int B, int C, int HW, int dtype, psg_stream_t stream) {
+    PSG_REQUIRE(src && dst, PSG_ERR_ARG, "nhwc_to_nchw: null pointer");
+    PSG_REQUIRE(B > 0 && C > 0 && HW > 0 && ld_src >= C, PSG_ERR_SHAPE, "nhwc_to_nchw: bad shape");
+    const int g = grid_for((int64_t)B * C * HW, 256);
+    DISPATCH_DTYPE(dtype,
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)src, ld_src, dst, B, C, HW),
+        hipLaunchKernelGGL(nhwc_to_nchw_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, ld_src, dst, B, C, HW));
+    PSG_LAUNCH_CHECK("nhwc_to_nchw");
+    return PSG_OK;
+}
+
+int psg_text_pool(const float* text, void* pooled, int64_t ld_pooled, void* text_cast, int B, int S, int D, int dtype,
+                  psg_stream_t stream) {
+    PSG_REQUIRE(text && pooled, PSG_ERR_ARG, "text_pool: null pointer");
+    PSG_REQUIRE(B > 0 && S > 0 && D > 0 && ld_pooled >= D, PSG_ERR_SHAPE, "text_pool: bad shape");
+    DISPATCH_DTYPE(dtype,
+        hipLaunchKernelGGL(text_pool_kernel<float>, dim3(B), dim3(256), 0, (hipStream_t)stream, text, (float*)pooled, ld_pooled, (float*)text_cast, B, S, D),
+        hipLaunchKernelGGL(text_pool_kernel<bf16_t>, dim3(B), dim3(256), 0, (hipStream_t)stream, text, (bf16_t*)pooled, ld_pooled, (bf16_t*)text_cast, B, S, D));
+    PSG_LAUNCH_CHECK("text_pool");
+    return PSG_OK;
+}
+
+int psg_timestep_sinusoid(const int64_t* t, const float* coeff, void* out, int64_t ld_out, int B, int half, int dtype,
+                          psg_stream_t stream) {
+    PSG_REQUIRE(t && coeff && out, PSG_ERR_ARG, "sinusoid: null pointer");
+    PSG_REQUIRE(B > 0 && half > 0 && ld_out >= 2 * half, PSG_ERR_SHAPE, "sinusoid: bad shape");
+    const int g = (B * half + 255) / 256;
+    DISPATCH_DTYPE(dtype,
+        hipLaunchKernelGGL(sinusoid_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, t, coeff, (float*)out, ld_out, B, half),
+        hipLaunchKernelGGL(sinusoid_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, t, coeff, (bf16_t*)out, ld_out, B, half));
+    PSG_LAUNCH_CHECK("sinusoid");
+    return PSG_OK;
+}
+
+int psg_upsample_bilinear_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, int B, int Hi, int Wi, int Ho, int Wo,
+                              int C, int dtype, psg_stream_t stream) {
+    PSG_REQUIRE(x && y, PSG_ERR_ARG, "upsample_fwd: null pointer");
+    PSG_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho >= Hi && Wo >= Wi && C > 0 && (C & 3) == 0 && ldx >= C && ldy >= C &&
+                (ldx & 3) == 0 && (ldy & 3) == 0, PSG_ERR_SHAPE, "upsample_fwd: bad shape (C, ld multiples of 4)");
+    const int g = grid_for((int64_t)B * Ho * Wo * (C / 4), 256, 8192);
+    DISPATCH_DTYPE(dtype,
+        hipLaunchKernelGGL(upsample_fwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (float*)y, ldy, B, Hi, Wi, Ho, Wo, C),
+        hipLaunchKernelGGL(upsample_fwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, B, Hi, Wi, Ho, Wo, C));
+    PSG_LAUNCH_CHECK("upsample_fwd");
+    return PSG_OK;
+}
+
+int psg_upsample_bilinear_bwd(const void* dy, int64_t lddy, void* dx, int64_t lddx, int B, int Hi, int Wi, int Ho,
+                              int Wo, int C, int dtype, psg_stream_t stream) {
+    PSG_REQUIRE(dy && dx, PSG_ERR_ARG, "upsample_bwd: null pointer");
+    PSG_REQUIRE(B > 0 && Hi > 0 && Wi > 0 && Ho >= Hi && Wo >= Wi && C > 0 && (C & 3) == 0 && lddy >= C && lddx >= C &&
+                (lddx & 3) == 0 && (lddy & 3) == 0, PSG_ERR_SHAPE, "upsample_bwd: bad shape (C, ld multiples of 4)");
+    const int g = grid_for((int64_t)B * Hi * Wi * (C / 4), 256, 8192);
+    DISPATCH_DTYPE(dtype,
+        hipLaunchKernelGGL(upsample_bwd_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)dy, lddy, (float*)dx, lddx, B, Hi, Wi, Ho, Wo, C),
+        hipLaunchKernelGGL(upsample_bwd_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, B, Hi, Wi, Ho, Wo, C));
+    PSG_LAUNCH_CHECK("upsample_bwd");
+    return PSG_OK;
+}
+
+int psg_add(const void* a, int64_t lda, const void* b, int64_t ldb, void* y, int64_t ldy, int64_t rows, int cols,
+            int dtype, psg_stream_t stream) {
+    PSG_REQUIRE(a && b && y, PSG_ERR_ARG, "add: null pointer");
+    PSG_REQUIRE(rows > 0 && cols > 0 && (cols & 3) == 0 && ((lda | ldb | ldy) & 3) == 0, PSG_ERR_SHAPE, "add: cols/ld must be multiples of 4");
+    const int g = grid_for(rows * (cols / 4), 256, 8192);
+    DISPATCH_DTYPE(dtype,
+        hipLaunchKernelGGL(add_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)a, lda, (const float*)b, ldb, (float*)y, ldy, rows, cols),
+        hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, (bf16_t*)y, ldy, rows, cols));
+    PSG_LAUNCH_CHECK("add");
+    return PSG_OK;
+}
+
+int psg_dropout_apply(const void* x, int64_t ldx, void* y, int64_t ldy, int64_t rows, int cols, float p, uint64_t seed,
+                      float scale, int dtype, psg_stream_t stream) {
+    PSG_REQUIRE(x && y, PSG_ERR_ARG, "dropout_apply: null pointer");
+    PSG_REQUIRE(rows > 0 && cols > 0 && (cols & 3) == 0 && ((ldx | ldy) & 3) == 0 && p >= 0.f && p < 1.f, PSG_ERR_SHAPE, "dropout_apply: bad shape");
+    const int g = grid_for(rows * (cols / 4), 256, 8192);
+    const uint32_t th = drop_thresh(p);
+    DISPATCH_DTYPE(dtype,
+        hipLaunchKernelGGL(dropout_apply_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (float*)y, ldy, rows, cols, th, seed, scale),
+        hipLaunchKernelGGL(dropout_apply_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, rows, cols, th, seed, scale));
+    PSG_LAUNCH_CHECK("dropout_apply");
+    return PSG_OK;
+}
+
+int psg_epilogue_bwd(const void* dy, int64_t lddy, const void* u, int64_t ldu, void* g, int64_t ldg, int64_t rows, int cols,
+                     int act, float alpha, float drop_p, uint64_t seed, int dtype, psg_stream_t stream) {
+    PSG_REQUIRE(dy && g && (u || act == PSG_ACT_NONE), PSG_ERR_ARG, "epilogue_bwd: null pointer");
+    PSG_REQUIRE(rows > 0 && cols > 0 && (cols & 3) == 0 && ((lddy | ldg) & 3) == 0 && (!u || (ldu & 3) == 0) && drop_p >= 0.f && drop_p < 1.f,
+                PSG_ERR_SHAPE, "epilogue_bwd: bad shape");
+    const int gr = grid_for(rows * (cols / 4), 256, 8192);
+    const uint32_t th = drop_p > 0.f ? drop_thresh(drop_p) : 0u;
+    const float ds = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    DISPATCH_DTYPE(dtype,
+        hipLaunchKernelGGL(epilogue_bwd_kernel<float>, dim3(gr), dim3(256), 0, (hipStream_t)stream, (const float*)dy, lddy, (const float*)u, ldu, (float*)g, ldg, rows, cols, act, alpha, th, ds, seed),
+        hipLaunchKernelGGL(epilogue_bwd_kernel<bf16_t>, dim3(gr), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, lddy, (const bf16_t*)u, ldu, (bf16_t*)g, ldg, rows, cols, act, alpha, th, ds, seed));
+    PSG_LAUNCH_CHECK("epilogue_bwd");
+    return PSG_OK;
+}
+
+int64_t psg_kpad(int64_t K, int dtype) {
+    const int64_t bk = dtype == PSG_BF16 ? 64 : 32;
+    return (K + bk - 1) / bk * bk;
+}
+
+int psg_prep_weight(const float* w, void* wf, void* wd, int O, int I, int ksize, int dtype, psg_stream_t stream) {
+    PSG_REQUIRE(w && (wf || wd), PSG_ERR_ARG, "prep_weight: null pointer");
+    PSG_REQUIRE(O > 0 && I > 0 && (ksize == 1 || ksize == 3), PSG_ERR_SHAPE, "prep_weight: O=%d I=%d k=%d", O, I, ksize);
+    const int taps = ksize * ksize;
+    const int64_t kpf = psg_kpad((int64_t)taps * I, dtype), kpd = psg_kpad((int64_t)taps * O, dtype);
+    int64_t n = 0;
+    if (wf) n = (int64_t)O * kpf;
+    if (wd && (int64_t)I * kpd > n) n = (int64_t)I * kpd;
+    const int g = grid_for(n, 256, 8192);
+    DISPATCH_DTYPE(dtype,
+        hipLaunchKernelGGL(prep_weight_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, w, (float*)wf, (float*)wd, O, I, taps, kpf, kpd),
+        hipLaunchKernelGGL(prep_weight_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)wf, (bf16_t*)wd, O, I, taps, kpf, kpd));
+    PSG_LAUNCH_CHECK("prep_weight");
+    return PSG_OK;
+}
+
+static inline void colsum_plan(int64_t R, int groups, int& splits, int64_t& rps) {
+    // aim for >= 512 row-splits*groups in flight, at least 32 rows per split
+    int64_t want = (512 + groups - 1) / groups;
+    int64_t maxs = (R + 31) / 32;
+    if (want > maxs) want = maxs;
+    if (want < 1) want = 1;
+    rps = (R + want - 1) / want;
+    splits = (int)((R + rps - 1) / rps);
+}
+
+int64_t psg_colsum_workspace_bytes(int64_t R, int groups, int cols) {
+    int splits; int64_t rps;
+    colsum_plan(R, groups, splits, rps);
+    return (int64_t)groups * splits * cols * sizeof(float);
+}
+
+int psg_colsum(const void* a, int64_t lda, void* out, int64_t ld_out, int64_t R, int groups, int cols, int dtype,
+               int out_dtype, int accumulate, void* ws, int64_t ws_bytes, psg_stream_t stream) {
+    PSG_REQUIRE(a && out && ws, PSG_ERR_ARG, "colsum: null pointer");
+    PSG_REQUIRE(R > 0 && groups > 0 && cols > 0 && lda >= cols && ld_out >= cols, PSG_ERR_SHAPE, "colsum: bad shape");
+    PSG_REQUIRE(ws_bytes >= psg_colsum_workspace_bytes(R, groups, cols), PSG_ERR_WORKSPACE, "colsum: workspace too small");
+    PSG_REQUIRE(!(accumulate && out_dtype != PSG_F32), PSG_ERR_ARG, "colsum: accumulate needs fp32 out");
+    int splits; int64_t rps;
+    colsum_plan(R, groups, splits, rps);
+    dim3 g1((cols + 63) / 64, groups * splits);
+    DISPATCH_DTYPE(dtype,
+        hipLaunchKernelGGL(colsum_stage1<float>, g1, dim3(64), 0, (hipStream_t)stream, (const float*)a, lda, (float*)ws, R, groups, cols, splits, rps),
+        hipLaunchKernelGGL(colsum_stage1<bf16_t>, g1, dim3(64), 0, (hipStream_t)stream, (const bf16_t*)a, lda, (float*)ws, R, groups, cols, splits, rps));
+    PSG_LAUNCH_CHECK("colsum_stage1");
+    const int g2 = grid_for((int64_t)groups * cols, 256);
+    DISPATCH_DTYPE(out_dtype,
+        hipLaunchKernelGGL(colsum_stage2<float>, dim3(g2), dim3(256), 0, (hipStream_t)stream, (const float*)ws, (float*)out, ld_out, groups, cols, splits, accumulate),
+        hipLaunchKernelGGL(colsum_stage2<bf16_t>, dim3(g2), dim3(256), 0, (hipStream_t)stream, (const float*)ws, (bf16_t*)out, ld_out, groups, cols, splits, accumulate));
+    PSG_LAUNCH_CHECK("colsum_stage2");
+    return PSG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,140 @@
+// Shared device/host helpers for libpsg_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include <math.h>
+
+#include "../../include/psg_hip.h"
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+namespace psg {
+
+int set_error(int code, const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define PSG_HIP_CHECK(expr)                                   \
+    do {                                                      \
+        hipError_t _e = (expr);                               \
+        if (_e != hipSuccess) return psg::hip_fail(_e, #expr); \
+    } while (0)
+#define PSG_LAUNCH_CHECK(name)                                 \
+    do {                                                       \
+        hipError_t _e = hipGetLastError();                     \
+        if (_e != hipSuccess) return psg::hip_fail(_e, name);  \
+    } while (0)
+#define PSG_REQUIRE(cond, code, ...)                              \
+    do {                                                          \
+        if (!(cond)) return psg::set_error(code, __VA_ARGS__);    \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
+
+// ---- element access -------------------------------------------------------
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+    static constexpr int CH = 4;  // elements per 16-byte chunk
+    static __device__ __forceinline__ float ld(const float* p) { return *p; }
+    static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct Elem<bf16_t> {
+    static constexpr int CH = 8;
+    static __device__ __forceinline__ float ld(const bf16_t* p) { return (float)*p; }
+    static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = (bf16_t)v; }
+};
+
+// 4 consecutive elements
+template <typename T> __device__ __forceinline__ f32x4 load4(const T* p);
+template <> __device__ __forceinline__ f32x4 load4<float>(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+template <> __device__ __forceinline__ f32x4 load4<bf16_t>(const bf16_t* p) {
+    bf16x4 v = *reinterpret_cast<const bf16x4*>(p);
+    f32x4 r = {(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+    return r;
+}
+template <typename T> __device__ __forceinline__ void store4(T* p, f32x4 v);
+template <> __device__ __forceinline__ void store4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+template <> __device__ __forceinline__ void store4<bf16_t>(bf16_t* p, f32x4 v) {
+    bf16x4 r = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
+    *reinterpret_cast<bf16x4*>(p) = r;
+}
+
+// ---- activations ------------------------------------------------------------
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float silu_f(float x) { return x * sigmoidf_(x); }
+__device__ __forceinline__ float silu_grad(float x) {
+    float s = sigmoidf_(x);
+    return s * (1.0f + x * (1.0f - s));
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad(float x) {
+    float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+__device__ __forceinline__ float act_f(float x, int act) {
+    return act == PSG_ACT_SILU ? silu_f(x) : (act == PSG_ACT_GELU ? gelu_f(x) : x);
+}
+__device__ __forceinline__ float act_grad(float x, int act) {
+    return act == PSG_ACT_SILU ? silu_grad(x) : (act == PSG_ACT_GELU ? gelu_grad(x) : 1.0f);
+}
+
+// ---- stateless dropout mask ---------------------------------------------------
+// keep(idx) = hash(seed, idx) >= p * 2^32 ; the same function regenerates the mask in backward.
+__device__ __forceinline__ uint32_t mix32(uint32_t h) {
+    h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
+    return h;
+}
+__device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
+    uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
+    uint32_t h = mix32(lo * 0x9E3779B1u + (uint32_t)seed);
+    h = mix32(h ^ (hi * 0x85EBCA77u + (uint32_t)(seed >> 32)));
+    return h >= thresh;
+}
+static inline uint32_t drop_thresh(float p) {
+    double t = (double)p * 4294967296.0;
+    if (t < 0) t = 0;
+    if (t > 4294967295.0) t = 4294967295.0;
+    return (uint32_t)t;
+}
+
+// ---- wave / block reductions ---------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+// block sum for blockDim.x multiple of 64, <= 1024; red: >= 16 floats of LDS; result broadcast.
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wid] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < nw; ++i) r += red[i];
+    return r;
+}
+
+// exact n / d for n < 2^24 using a float reciprocal and one correction step
+__device__ __forceinline__ int fastdiv(int n, int d, float inv_d) {
+    int q = (int)((float)n * inv_d);
+    int r = n - q * d;
+    if (r < 0) { --q; r += d; }
+    if (r >= d) ++q;
+    return q;
+}
+
+}  // namespace psg

@@ -1,0 +1,284 @@
+// Weight gradient of conv / linear layers on the gfx950 matrix cores.
+//
+//   dW[co, q] = sum_m dY[m, co] * X[pix(m, tap(q)), ci(q)],   q = tap*Cin + ci
+//
+// Both operands are stored with the REDUCTION index (pixel m) as the slow
+// dimension (channels-last), i.e. this is a "TN" GEMM.  Tiles [pixels][128 ch]
+// of dY and of the gathered X are register-staged into LDS as they lie in
+// memory; the MFMA fragments (which need 8 consecutive reduction indices per
+// lane) are produced by the hardware transposing LDS read ds_read_b64_tr_b16
+// (bf16; row stride 320 B makes the 4x16 blocks of a half-wave hit 64 distinct
+// banks) or by plain ds_read_b32 (fp32 v_mfma_f32_32x32x2_f32 takes one value
+// per lane).  Output tile 128(co) x 128(q) per 256-thread workgroup, columns
+// tiled over the flat q axis (so Cin=320 wastes nothing), split-K over pixels
+// with fp32 partial slabs and a deterministic reduce+permute pass that writes
+// the OIHW fp32 gradient.
+#include "psg_common.h"
+
+namespace psg {
+
+struct WgP {
+    const void* x; const void* dy; float* ws;
+    int64_t ldx, lddy;
+    int B, Hi, Wi, Cin, Ho, Wo, Cout, ks, stride, pad;
+    int M, Q, taps;
+    int rtiles, qtiles, splits, steps_per_split;   // steps of BKP pixels
+    float inv_HoWo, inv_Wo;
+};
+
+template <typename T> struct WgCfg;
+template <> struct WgCfg<bf16_t> { static constexpr int BKP = 64; static constexpr int ROWB = 320; };  // bytes per LDS row
+template <> struct WgCfg<float> { static constexpr int BKP = 32; static constexpr int ROWB = 512; };
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
+    constexpr int CH = Elem<T>::CH;
+    constexpr int BKP = WgCfg<T>::BKP;
+    constexpr int ROWB = WgCfg<T>::ROWB;
+    constexpr int CPR = 128 / CH;            // 16-byte chunks per 128-channel row
+    constexpr int RPP = 256 / CPR;           // rows per staging pass
+    constexpr int NPASS = BKP / RPP;         // = 4
+    constexpr int TILE_BYTES = BKP * ROWB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [buf][A tile | B tile]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave & 1, wc = wave >> 1;
+
+    // block -> (row tile, col tile, split); splits fastest so partial slabs of a tile are neighbours
+    int bid = blockIdx.x;
+    const int split = bid % p.splits; bid /= p.splits;
+    const int rt = bid % p.rtiles; const int qt = bid / p.rtiles;
+    const int co0 = rt * 128, q0 = qt * 128;
+
+    const int sc = tid % CPR, sr = tid / CPR;
+    const T* xg = reinterpret_cast<const T*>(p.x);
+    const T* dyg = reinterpret_cast<const T*>(p.dy);
+
+    // A operand (dY): column chunk -> co
+    const int a_co = co0 + sc * CH;
+    const bool a_ok = a_co < p.Cout;
+    // B operand (X gathered): column chunk -> (tap, ci)
+    const int b_q = q0 + sc * CH;
+    const bool b_ok = b_q < p.Q;
+    const int b_tap = b_ok ? b_q / p.Cin : 0;
+    const int b_ci = b_q - b_tap * p.Cin;
+    const int b_kh = b_tap / p.ks, b_kw = b_tap - b_kh * p.ks;
+    const int HoWo = p.Ho * p.Wo;
+
+    const int step0 = split * p.steps_per_split;
+    const int total_steps = (p.M + BKP - 1) / BKP;
+    int nsteps = total_steps - step0;
+    if (nsteps > p.steps_per_split) nsteps = p.steps_per_split;
+
+    uint4 ga[NPASS], gb[NPASS];
+    auto load_tiles = [&](int step) {
+        const int mbase = (step0 + step) * BKP;
+#pragma unroll
+        for (int j = 0; j < NPASS; ++j) {
+            const int m = mbase + sr + RPP * j;
+            const bool m_ok = m < p.M;
+            ga[j] = (m_ok && a_ok) ? *reinterpret_cast<const uint4*>(dyg + (int64_t)m * p.lddy + a_co) : make_uint4(0, 0, 0, 0);
+            bool ok = m_ok && b_ok;
+            int64_t off = 0;
+            if (ok) {
+                const int b = fastdiv(m, HoWo, p.inv_HoWo), rm = m - b * HoWo;
+                const int ho = fastdiv(rm, p.Wo, p.inv_Wo), wo = rm - ho * p.Wo;
+                const int sh = ho * p.stride - p.pad + b_kh, sw = wo * p.stride - p.pad + b_kw;
+                ok = sh >= 0 && sw >= 0 && sh < p.Hi && sw < p.Wi;
+                off = (int64_t)((b * p.Hi + sh) * p.Wi + sw) * p.ldx + b_ci;
+            }
+            gb[j] = ok ? *reinterpret_cast<const uint4*>(xg + off) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+        char* base = smem + buf * 2 * TILE_BYTES;
+#pragma unroll
+        for (int j = 0; j < NPASS; ++j) {
+            const int row = sr + RPP * j;
+            *reinterpret_cast<uint4*>(base + row * ROWB + sc * 16) = ga[j];
+            *reinterpret_cast<uint4*>(base + TILE_BYTES + row * ROWB + sc * 16) = gb[j];
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (nsteps > 0) {
+        load_tiles(0);
+        store_tiles(0);
+    }
+    __syncthreads();
+
+    for (int st = 0; st < nsteps; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nsteps) load_tiles(st + 1);
+        const char* ab = smem + buf * 2 * TILE_BYTES;
+        const char* bb = ab + TILE_BYTES;
+        if constexpr (sizeof(T) == 2) {
+            // lane -> (16-lane group g, q4 = row of the 4x16 block, p4 = 4-column piece)
+            const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
+            const int krow = (g >> 1) * 8 + q4;             // + 16*kk + 4*u
+            const int ccol = (g & 1) * 16 + p4 * 4;         // + tile column base
+#pragma unroll
+            for (int kk = 0; kk < BKP / 16; ++kk) {
+                bf16x8 af[2], bf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int colA = wr * 64 + i * 32 + ccol;
+                    const int colB = wc * 64 + i * 32 + ccol;
+                    s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ab + (kk * 16 + krow) * ROWB + colA * 2));
+                    s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ab + (kk * 16 + krow + 4) * ROWB + colA * 2));
+                    s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(bb + (kk * 16 + krow) * ROWB + colB * 2));
+                    s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(bb + (kk * 16 + krow + 4) * ROWB + colB * 2));
+                    typedef __attribute__((ext_vector_type(8))) short s16x8;
+                    s16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                    s16x8 bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                    af[i] = *reinterpret_cast<bf16x8*>(&av);
+                    bf[i] = *reinterpret_cast<bf16x8*>(&bv);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        } else {
+            const int fr = lane & 31, fh = lane >> 5;
+#pragma unroll 4
+            for (int kk = 0; kk < BKP / 2; ++kk) {
+                float af[2], bf[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[i] = *reinterpret_cast<const float*>(ab + (kk * 2 + fh) * ROWB + (wr * 64 + i * 32 + fr) * 4);
+                    bf[i] = *reinterpret_cast<const float*>(bb + (kk * 2 + fh) * ROWB + (wc * 64 + i * 32 + fr) * 4);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (st + 1 < nsteps) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // partial slab: ws[split][co][q]
+    const int fr = lane & 31, fh = lane >> 5;
+    float* wsb = p.ws + (int64_t)split * p.Cout * p.Q;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int q = q0 + wc * 64 + j * 32 + fr;
+        if (q >= p.Q) continue;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                if (co < p.Cout) wsb[(int64_t)co * p.Q + q] = acc[i][j][r];
+            }
+        }
+    }
+}
+
+// dw[co][ci][tap] (+)= sum_s ws[s][co][tap*Cin + ci]; one block per (co, 256-ci chunk), LDS transpose
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Cin, int taps,
+                                    int splits, int accumulate) {
+    __shared__ float tile[9 * 256];
+    const int co = blockIdx.x;
+    const int ci0 = blockIdx.y * 256;
+    const int nci = min(256, Cin - ci0);
+    const int64_t Q = (int64_t)taps * Cin;
+    const int64_t slab = (int64_t)Cout * Q;
+    for (int e = threadIdx.x; e < taps * nci; e += blockDim.x) {
+        const int tap = e / nci, ci = e - tap * nci;
+        const float* src = ws + (int64_t)co * Q + (int64_t)tap * Cin + ci0 + ci;
+        float a = 0.f;
+        for (int s = 0; s < splits; ++s) a += src[(int64_t)s * slab];
+        tile[ci * taps + tap] = a;
+    }
+    __syncthreads();
+    float* dst = dw + ((int64_t)co * Cin + ci0) * taps;
+    for (int e = threadIdx.x; e < taps * nci; e += blockDim.x) {
+        float v = tile[e];
+        if (accumulate) v += dst[e];
+        dst[e] = v;
+    }
+}
+
+static void wgrad_plan(const psg_wgrad_desc* d, WgP& p) {
+    const int BKP = d->dtype == PSG_BF16 ? 64 : 32;
+    p.M = d->B * d->Ho * d->Wo;
+    p.taps = d->ksize * d->ksize;
+    p.Q = p.taps * d->Cin;
+    p.rtiles = (d->Cout + 127) / 128;
+    p.qtiles = (p.Q + 127) / 128;
+    const int total_steps = (p.M + BKP - 1) / BKP;
+    const int tiles = p.rtiles * p.qtiles;
+    int want = (1024 + tiles - 1) / tiles;          // ~4 workgroups per CU in flight
+    const int max_splits = (total_steps + 7) / 8;   // at least 8 K steps per split
+    if (want > max_splits) want = max_splits;
+    if (want < 1) want = 1;
+    p.steps_per_split = (total_steps + want - 1) / want;
+    p.splits = (total_steps + p.steps_per_split - 1) / p.steps_per_split;
+}
+
+}  // namespace psg
+using namespace psg;
+
+extern "C" {
+
+int psg_wgrad_init_attrs(void) {
+    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 320));
+    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32 * 512));
+    return PSG_OK;
+}
+
+static int wgrad_check(const psg_wgrad_desc* d) {
+    PSG_REQUIRE(d, PSG_ERR_ARG, "wgrad: null descriptor");
+    PSG_REQUIRE(d->dtype == PSG_F32 || d->dtype == PSG_BF16, PSG_ERR_DTYPE, "wgrad: dtype %d", d->dtype);
+    const int CH = d->dtype == PSG_BF16 ? 8 : 4;
+    PSG_REQUIRE(d->B > 0 && d->Hi > 0 && d->Wi > 0 && d->Cin > 0 && d->Ho > 0 && d->Wo > 0 && d->Cout > 0, PSG_ERR_SHAPE, "wgrad: non-positive dimension");
+    PSG_REQUIRE((d->ksize == 1 && d->pad == 0) || (d->ksize == 3 && d->pad == 1), PSG_ERR_SHAPE, "wgrad: ksize/pad");
+    PSG_REQUIRE(d->stride == 1 || d->stride == 2, PSG_ERR_SHAPE, "wgrad: stride");
+    PSG_REQUIRE(d->Ho == (d->Hi + 2 * d->pad - d->ksize) / d->stride + 1 && d->Wo == (d->Wi + 2 * d->pad - d->ksize) / d->stride + 1, PSG_ERR_SHAPE, "wgrad: geometry");
+    PSG_REQUIRE(d->Cin % CH == 0 && d->Cout % CH == 0, PSG_ERR_SHAPE, "wgrad: Cin=%d Cout=%d must be multiples of %d", d->Cin, d->Cout, CH);
+    PSG_REQUIRE(d->ldx >= d->Cin && d->ldx % CH == 0 && d->lddy >= d->Cout && d->lddy % CH == 0, PSG_ERR_SHAPE, "wgrad: row strides");
+    PSG_REQUIRE((int64_t)d->B * d->Ho * d->Wo < (1 << 24) && (int64_t)d->B * d->Hi * d->Wi < (1ll << 30), PSG_ERR_SHAPE, "wgrad: too many pixels");
+    return PSG_OK;
+}
+
+int64_t psg_conv_wgrad_workspace_bytes(const psg_wgrad_desc* d) {
+    if (wgrad_check(d) != PSG_OK) return -1;
+    WgP p;
+    wgrad_plan(d, p);
+    return (int64_t)p.splits * d->Cout * p.Q * sizeof(float);
+}
+
+int psg_conv_wgrad(const psg_wgrad_desc* d, psg_stream_t stream) {
+    int rc = wgrad_check(d);
+    if (rc) return rc;
+    PSG_REQUIRE(d->x && d->dy && d->dw && d->ws, PSG_ERR_ARG, "wgrad: null pointer");
+    PSG_REQUIRE(aligned16(d->x) && aligned16(d->dy) && aligned16(d->ws), PSG_ERR_ALIGN, "wgrad: x/dy/ws must be 16-byte aligned");
+    WgP p;
+    wgrad_plan(d, p);
+    PSG_REQUIRE(d->ws_bytes >= (int64_t)p.splits * d->Cout * p.Q * (int64_t)sizeof(float), PSG_ERR_WORKSPACE, "wgrad: workspace too small");
+    p.x = d->x; p.dy = d->dy; p.ws = (float*)d->ws; p.ldx = d->ldx; p.lddy = d->lddy;
+    p.B = d->B; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
+    p.ks = d->ksize; p.stride = d->stride; p.pad = d->pad;
+    p.inv_HoWo = 1.0f / (float)(d->Ho * d->Wo); p.inv_Wo = 1.0f / (float)d->Wo;
+    const int grid = p.rtiles * p.qtiles * p.splits;
+    hipStream_t s = (hipStream_t)stream;
+    if (d->dtype == PSG_BF16) hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3(grid), dim3(256), 4 * 64 * 320, s, p);
+    else hipLaunchKernelGGL(wgrad_kernel<float>, dim3(grid), dim3(256), 4 * 32 * 512, s, p);
+    PSG_LAUNCH_CHECK("wgrad");
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(d->Cout, (d->Cin + 255) / 256), dim3(256), 0, s, (const float*)d->ws, d->dw,
+                       d->Cout, d->Cin, p.taps, p.splits, d->accumulate);
+    PSG_LAUNCH_CHECK("wgrad_reduce");
+    return PSG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,474 @@
+"""torch.autograd.Function wrappers over the C ABI (libpsg_hip.so).
+
+All activations are channels-last: a conv tensor is [B, H, W, C], a token tensor
+[B, L, C]; the last dim is contiguous and rows have a uniform stride.  Every op
+here launches hand-written HIP kernels on torch's current stream; PyTorch only
+owns the memory.  There is no eager fallback: tensors must be on a GPU.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import ACT_GELU, ACT_NONE, ACT_SILU, ConvDesc, WgradDesc, check, dtype_code, ptr, stream_ptr
+
+__all__ = ["conv2d", "linear", "group_norm", "attention_self", "attention_cross", "cross_in_proj", "upsample_bilinear",
+           "nchw_to_nhwc", "nhwc_to_nchw", "text_pool", "timestep_sinusoid", "WeightCache", "ACT_NONE", "ACT_SILU", "ACT_GELU"]
+
+
+def _lib_for(t):
+    if not t.is_cuda:
+        raise _lib.PsgError("pokemon_sprite_generator_amd ops need GPU tensors: the HIP kernels are the only implementation")
+    return _lib.init(t.device.index if t.device.index is not None else torch.cuda.current_device())
+
+
+def _rows(t):
+    """Collapse [..., C] with uniform row stride to (rows, ld); copies if the layout is irregular."""
+    if t.stride(-1) != 1:
+        t = t.contiguous()
+    C_ = t.shape[-1]
+    ld = t.stride(-2) if t.dim() >= 2 else C_
+    ok = True
+    expect = ld
+    for i in range(t.dim() - 2, -1, -1):
+        if t.shape[i] != 1 and t.stride(i) != expect:
+            ok = False
+            break
+        expect = expect * t.shape[i]
+    if not ok or (t.data_ptr() % 16) != 0 or (ld % 8) != 0:
+        t = t.contiguous()
+        ld = C_
+    return t, ld
+
+
+# ---------------------------------------------------------------------------
+# prepared-weight cache
+# ---------------------------------------------------------------------------
+class WeightCache:
+    """fp32 OIHW master weight -> kernel-layout weights in the compute dtype.
+
+    wf: [O][Kpad] with k=(kh,kw,ci) for the forward gather, wd: [I][Kpad'] with
+    k=(kh,kw,co) for the data-gradient gather (psg_prep_weight).  Entries are
+    keyed on the parameter's storage, its torch version counter and a global
+    epoch that optimizers writing through raw pointers bump (invalidate()).
+    """
+    epoch = 0
+    _entries = {}
+
+    @classmethod
+    def invalidate(cls):
+        cls.epoch += 1
+
+    @classmethod
+    def clear(cls):
+        cls._entries.clear()
+        cls.epoch += 1
+
+    @classmethod
+    def get(cls, w, dtype, need_wd):
+        key = id(w)
+        stamp = (w.data_ptr(), w._version, cls.epoch, dtype)
+        ent = cls._entries.get(key)
+        if ent is not None and ent[0] == stamp and (ent[2] is not None or not need_wd):
+            return ent[1], ent[2]
+        lib = _lib_for(w)
+        O, I = w.shape[0], w.shape[1]
+        ks = w.shape[2] if w.dim() == 4 else 1
+        code = dtype_code(dtype)
+        kpf = lib.psg_kpad(ks * ks * I, code)
+        kpd = lib.psg_kpad(ks * ks * O, code)
+        wf = torch.empty((O, kpf), dtype=dtype, device=w.device)
+        wd = torch.empty((I, kpd), dtype=dtype, device=w.device) if need_wd else None
+        src = w.detach()
+        if not src.is_contiguous():
+            src = src.contiguous()
+        check(lib.psg_prep_weight(ptr(src), ptr(wf), ptr(wd), O, I, ks, code, stream_ptr()), "psg_prep_weight")
+        cls._entries[key] = (stamp, wf, wd, w)   # keep w alive so id() stays unique
+        return wf, wd
+
+
+def _conv_launch(lib, dtype, x, ldx, w, ldw, y, ldy, geom, Cin, Cout, transposed=False, bias=None, rowadd=None,
+                 residual=None, ld_res=0, preact=None, dact_u=None, ld_dact=0, act=ACT_NONE, alpha=1.0, drop_p=0.0, seed=0):
+    B, Hi, Wi, Ho, Wo, ks, stride, pad = geom
+    d = ConvDesc()
+    d.dtype = dtype_code(dtype)
+    d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout = B, Hi, Wi, Cin, Ho, Wo, Cout
+    d.ksize, d.stride, d.pad, d.transposed, d.act = ks, stride, pad, int(transposed), act
+    d.alpha, d.drop_p, d.drop_seed = float(alpha), float(drop_p), int(seed)
+    d.ldx, d.ldy, d.ldw = ldx, ldy, ldw
+    d.x, d.w, d.y = x.data_ptr(), w if isinstance(w, int) else w.data_ptr(), y.data_ptr()
+    d.bias = bias.data_ptr() if bias is not None else None
+    if rowadd is not None:
+        d.rowadd, d.ld_rowadd = rowadd.data_ptr(), rowadd.stride(0)
+    if residual is not None:
+        d.residual, d.ld_residual = residual.data_ptr(), ld_res
+    if preact is not None:
+        d.preact, d.ld_preact = preact.data_ptr(), preact.stride(-2)
+    if dact_u is not None:
+        d.dact_u, d.ld_dact = dact_u.data_ptr(), ld_dact
+    check(lib.psg_conv_fwd(C.byref(d), stream_ptr()), "psg_conv_fwd")
+
+
+def _wgrad_launch(lib, dtype, x, ldx, dy, lddy, dw, geom, Cin, Cout, accumulate=False):
+    B, Hi, Wi, Ho, Wo, ks, stride, pad = geom
+    d = WgradDesc()
+    d.dtype = dtype_code(dtype)
+    d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout = B, Hi, Wi, Cin, Ho, Wo, Cout
+    d.ksize, d.stride, d.pad, d.accumulate = ks, stride, pad, int(accumulate)
+    d.ldx, d.lddy = ldx, lddy
+    d.x, d.dy, d.dw = x.data_ptr(), dy.data_ptr(), dw.data_ptr()
+    need = lib.psg_conv_wgrad_workspace_bytes(C.byref(d))
+    if need < 0:
+        check(-1, "psg_conv_wgrad_workspace_bytes")
+    ws = _lib.workspace(need, x.device)
+    d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
+    check(lib.psg_conv_wgrad(C.byref(d), stream_ptr()), "psg_conv_wgrad")
+
+
+def _colsum(lib, a, lda, R, groups, cols, dtype, out_dtype):
+    out = torch.empty((groups, cols) if groups > 1 else (cols,), dtype=out_dtype, device=a.device)
+    need = lib.psg_colsum_workspace_bytes(R, groups, cols)
+    ws = _lib.workspace(need, a.device)
+    check(lib.psg_colsum(ptr(a), lda, ptr(out), cols, R, groups, cols, dtype_code(dtype), dtype_code(out_dtype), 0,
+                         ptr(ws), ws.numel(), stream_ptr()), "psg_colsum")
+    return out
+
+
+# ---------------------------------------------------------------------------
+# conv / linear
+# ---------------------------------------------------------------------------
+class _ConvFn(torch.autograd.Function):
+    """y = residual + alpha * drop(act(conv(x, W) + bias + rowadd[b]))  — psg_conv_fwd / psg_conv_wgrad."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, rowadd, residual, stride, act, alpha, drop_p, seed):
+        lib = _lib_for(x)
+        dtype = x.dtype
+        is_conv = weight.dim() == 4
+        Cout, Cin = weight.shape[0], weight.shape[1]
+        ks = weight.shape[2] if is_conv else 1
+        pad = 1 if ks == 3 else 0
+        xr, ldx = _rows(x)
+        if is_conv:
+            B, Hi, Wi = x.shape[0], x.shape[1], x.shape[2]
+            Ho, Wo = (Hi + 2 * pad - ks) // stride + 1, (Wi + 2 * pad - ks) // stride + 1
+            out_shape = (B, Ho, Wo, Cout)
+        else:
+            B, Hi, Wi, Ho, Wo = xr.numel() // xr.shape[-1], 1, 1, 1, 1
+            out_shape = tuple(x.shape[:-1]) + (Cout,)
+        geom = (B, Hi, Wi, Ho, Wo, ks, stride, pad)
+        need_dx = ctx.needs_input_grad[0]
+        wf, wd = WeightCache.get(weight, dtype, need_dx and torch.is_grad_enabled())
+        y = torch.empty(out_shape, dtype=dtype, device=x.device)
+        has_epi = (act != ACT_NONE)
+        any_grad = any(ctx.needs_input_grad)
+        preact = torch.empty(out_shape, dtype=dtype, device=x.device) if (has_epi and any_grad) else None
+        res_r, ld_res = (None, 0)
+        if residual is not None:
+            res_r, ld_res = _rows(residual)
+        ra = None
+        if rowadd is not None:
+            ra = rowadd if (rowadd.stride(-1) == 1 and rowadd.stride(0) % 4 == 0 and rowadd.data_ptr() % 16 == 0) else rowadd.contiguous()
+        _conv_launch(lib, dtype, xr, ldx, wf, 0, y, Cout, geom, Cin, Cout, bias=bias, rowadd=ra, residual=res_r, ld_res=ld_res,
+                     preact=preact, act=act, alpha=alpha, drop_p=drop_p, seed=seed)
+        ctx.save_for_backward(xr, weight, preact)
+        ctx.meta = (geom, Cin, Cout, ldx, act, alpha, drop_p, seed, bias is not None, rowadd is not None, residual is not None, tuple(x.shape), wd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xr, weight, preact = ctx.saved_tensors
+        geom, Cin, Cout, ldx, act, alpha, drop_p, seed, has_bias, has_ra, has_res, x_shape, wd = ctx.meta
+        B, Hi, Wi, Ho, Wo, ks, stride, pad = geom
+        lib = _lib_for(dy)
+        dtype = dy.dtype
+        dyr, lddy = _rows(dy)
+        M = B * Ho * Wo
+        d_res = dy if has_res else None
+        # gradient w.r.t. the pre-epilogue accumulator
+        if act != ACT_NONE or drop_p > 0.0 or alpha != 1.0:
+            g = torch.empty((M, Cout), dtype=dtype, device=dy.device)
+            check(lib.psg_epilogue_bwd(ptr(dyr), lddy, ptr(preact), Cout, ptr(g), Cout, M, Cout, act, float(alpha), float(drop_p),
+                                       int(seed), dtype_code(dtype), stream_ptr()), "psg_epilogue_bwd")
+            ldg = Cout
+        else:
+            g, ldg = dyr, lddy
+        dx = dw = db = dra = None
+        if ctx.needs_input_grad[0]:
+            if wd is None:
+                _, wd = WeightCache.get(weight, dtype, True)
+            dx = torch.empty(x_shape, dtype=dtype, device=dy.device)
+            tgeom = (B, Ho, Wo, Hi, Wi, ks, stride, pad)     # gather source = dY grid, result = input grid
+            _conv_launch(lib, dtype, g, ldg, wd, 0, dx, Cin, tgeom, Cout, Cin, transposed=True)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight)
+            _wgrad_launch(lib, dtype, xr, ldx, g, ldg, dw, geom, Cin, Cout)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = _colsum(lib, g, ldg, M, 1, Cout, dtype, torch.float32)
+        if has_ra and ctx.needs_input_grad[3]:
+            dra = _colsum(lib, g, ldg, Ho * Wo, B, Cout, dtype, dtype)
+        return dx, dw, db, dra, d_res, None, None, None, None, None
+
+
+def conv2d(x, weight, bias=None, stride=1, rowadd=None, residual=None, act=ACT_NONE, alpha=1.0, drop_p=0.0, seed=0):
+    """x: [B,H,W,Cin] channels-last; weight: fp32 OIHW parameter (3x3 pad 1, or 1x1).  nn.Conv2d of unet.py."""
+    return _ConvFn.apply(x, weight, bias, rowadd, residual, stride, act, alpha, drop_p, seed)
+
+
+def linear(x, weight, bias=None, residual=None, act=ACT_NONE, alpha=1.0, drop_p=0.0, seed=0):
+    """x: [..., Cin]; weight: fp32 [Cout, Cin] parameter.  nn.Linear of unet.py, with the fused epilogue."""
+    return _ConvFn.apply(x, weight, bias, None, residual, 1, act, alpha, drop_p, seed)
+
+
+class _CrossInProjFn(torch.autograd.Function):
+    """Packed MHA in-projection for cross-attention (unet.py:235 -> F.multi_head_attention_forward):
+    q = xn @ W[:E]^T + b[:E];  kv = tp @ W[E:]^T + b[E:]  with ONE packed parameter [3E, E]."""
+
+    @staticmethod
+    def forward(ctx, xn, tp, weight, bias):
+        lib = _lib_for(xn)
+        dtype = xn.dtype
+        E = weight.shape[1]
+        wf, wd = WeightCache.get(weight, dtype, torch.is_grad_enabled())
+        xr, ldx = _rows(xn)
+        tr, ldt = _rows(tp)
+        Mq, Mk = xn.numel() // E, tp.numel() // E
+        q = torch.empty(tuple(xn.shape[:-1]) + (E,), dtype=dtype, device=xn.device)
+        kv = torch.empty(tuple(tp.shape[:-1]) + (2 * E,), dtype=dtype, device=xn.device)
+        kp = wf.shape[1]
+        esz = wf.element_size()
+        _conv_launch(lib, dtype, xr, ldx, wf.data_ptr(), 0, q, E, (Mq, 1, 1, 1, 1, 1, 1, 0), E, E, bias=bias[:E])
+        _conv_launch(lib, dtype, tr, ldt, wf.data_ptr() + E * kp * esz, 0, kv, 2 * E, (Mk, 1, 1, 1, 1, 1, 1, 0), E, 2 * E, bias=bias[E:])
+        ctx.save_for_backward(xr, tr, weight)
+        ctx.meta = (E, ldx, ldt, Mq, Mk, tuple(xn.shape), tuple(tp.shape), wd, wf)
+        return q, kv
+
+    @staticmethod
+    def backward(ctx, dq, dkv):
+        xr, tr, weight = ctx.saved_tensors
+        E, ldx, ldt, Mq, Mk, xs, ts, wd, wf = ctx.meta
+        lib = _lib_for(dq)
+        dtype = dq.dtype
+        dqr, lddq = _rows(dq)
+        dkr, lddk = _rows(dkv)
+        if wd is None:
+            _, wd = WeightCache.get(weight, dtype, True)
+        kpd = wd.shape[1]
+        esz = wd.element_size()
+        dxn = dtp = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dxn = torch.empty(xs, dtype=dtype, device=dq.device)
+            _conv_launch(lib, dtype, dqr, lddq, wd.data_ptr(), kpd, dxn, E, (Mq, 1, 1, 1, 1, 1, 1, 0), E, E, transposed=True)
+        if ctx.needs_input_grad[1]:
+            dtp = torch.empty(ts, dtype=dtype, device=dq.device)
+            _conv_launch(lib, dtype, dkr, lddk, wd.data_ptr() + E * esz, kpd, dtp, E, (Mk, 1, 1, 1, 1, 1, 1, 0), 2 * E, E, transposed=True)
+        if ctx.needs_input_grad[2]:
+            dw = torch.empty_like(weight)
+            _wgrad_launch(lib, dtype, xr, ldx, dqr, lddq, dw[:E], (Mq, 1, 1, 1, 1, 1, 1, 0), E, E)
+            _wgrad_launch(lib, dtype, tr, ldt, dkr, lddk, dw[E:], (Mk, 1, 1, 1, 1, 1, 1, 0), E, 2 * E)
+        if ctx.needs_input_grad[3]:
+            db = torch.cat([_colsum(lib, dqr, lddq, Mq, 1, E, dtype, torch.float32),
+                            _colsum(lib, dkr, lddk, Mk, 1, 2 * E, dtype, torch.float32)])
+        return dxn, dtp, dw, db
+
+
+def cross_in_proj(xn, tp, weight, bias):
+    return _CrossInProjFn.apply(xn, tp, weight, bias)
+
+
+# ---------------------------------------------------------------------------
+# GroupNorm (+SiLU)
+# ---------------------------------------------------------------------------
+class _GroupNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps, silu):
+        lib = _lib_for(x)
+        dtype = x.dtype
+        xr, ldx = _rows(x)
+        B, Cc = x.shape[0], x.shape[-1]
+        HW = x.numel() // (B * Cc)
+        y = torch.empty(x.shape, dtype=dtype, device=x.device)
+        stats = torch.empty((2, B * groups), dtype=torch.float32, device=x.device)
+        check(lib.psg_groupnorm_fwd(ptr(xr), ldx, ptr(y), Cc, ptr(gamma), ptr(beta), ptr(stats[0]), ptr(stats[1]), B, HW, Cc, groups,
+                                    float(eps), int(silu), dtype_code(dtype), stream_ptr()), "psg_groupnorm_fwd")
+        ctx.save_for_backward(xr, gamma, beta, stats)
+        ctx.meta = (B, HW, Cc, groups, silu, ldx, tuple(x.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xr, gamma, beta, stats = ctx.saved_tensors
+        B, HW, Cc, groups, silu, ldx, shape = ctx.meta
+        lib = _lib_for(dy)
+        dtype = dy.dtype
+        dyr, lddy = _rows(dy)
+        dx = torch.empty(shape, dtype=dtype, device=dy.device)
+        dg = torch.empty(Cc, dtype=torch.float32, device=dy.device)
+        db = torch.empty(Cc, dtype=torch.float32, device=dy.device)
+        ws = _lib.workspace(lib.psg_groupnorm_bwd_workspace_bytes(B, Cc), dy.device)
+        check(lib.psg_groupnorm_bwd(ptr(dyr), lddy, ptr(xr), ldx, ptr(gamma), ptr(beta), ptr(stats[0]), ptr(stats[1]), ptr(dx), Cc,
+                                    ptr(dg), ptr(db), B, HW, Cc, groups, int(silu), 0, dtype_code(dtype), ptr(ws), stream_ptr()),
+              "psg_groupnorm_bwd")
+        return dx, dg, db, None, None, None
+
+
+def group_norm(x, gamma, beta, groups, eps=1e-5, silu=False):
+    """nn.GroupNorm (+F.silu) on channels-last [B, ..., C]: unet.py:115,127,214,231,397."""
+    return _GroupNormFn.apply(x, gamma, beta, groups, eps, silu)
+
+
+# ---------------------------------------------------------------------------
+# attention core
+# ---------------------------------------------------------------------------
+class _AttnFn(torch.autograd.Function):
+    """softmax((q/sqrt(d)) k^T) v for packed projections.  self: qkv [B,L,3E]; cross: q [B,L,E], kv [B,S,2E]."""
+
+    @staticmethod
+    def forward(ctx, q_src, kv_src, heads, drop_p, seed):
+        lib = _lib_for(q_src)
+        dtype = q_src.dtype
+        self_mode = kv_src is None
+        qr, ldq = _rows(q_src)
+        B, L = q_src.shape[0], q_src.shape[1]
+        esz = qr.element_size()
+        if self_mode:
+            E = q_src.shape[-1] // 3
+            S = L
+            kp, vp, ldk = qr.data_ptr() + E * esz, qr.data_ptr() + 2 * E * esz, ldq
+            kvr = None
+        else:
+            E = q_src.shape[-1]
+            kvr, ldk = _rows(kv_src)
+            S = kv_src.shape[1]
+            kp, vp = kvr.data_ptr(), kvr.data_ptr() + E * esz
+        d = E // heads
+        scale = float(d) ** -0.5
+        o = torch.empty((B, L, E), dtype=dtype, device=q_src.device)
+        lse = torch.empty((B, heads, L), dtype=torch.float32, device=q_src.device)
+        check(lib.psg_attn_fwd(qr.data_ptr(), ldq, kp, ldk, vp, ldk, ptr(o), E, ptr(lse), B, heads, L, S, d, scale, float(drop_p),
+                               int(seed), dtype_code(dtype), stream_ptr()), "psg_attn_fwd")
+        ctx.save_for_backward(qr, kvr, o, lse)
+        ctx.meta = (self_mode, B, L, S, E, heads, d, scale, drop_p, seed, ldq, ldk, tuple(q_src.shape), None if self_mode else tuple(kv_src.shape))
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        qr, kvr, o, lse = ctx.saved_tensors
+        self_mode, B, L, S, E, heads, d, scale, drop_p, seed, ldq, ldk, qshape, kvshape = ctx.meta
+        lib = _lib_for(do)
+        dtype = do.dtype
+        dor, lddo = _rows(do)
+        esz = qr.element_size()
+        delta = torch.empty((B, heads, L), dtype=torch.float32, device=do.device)
+        if self_mode:
+            dqkv = torch.empty(qshape, dtype=dtype, device=do.device)
+            W3 = 3 * E
+            kp, vp = qr.data_ptr() + E * esz, qr.data_ptr() + 2 * E * esz
+            dqp, dkp, dvp, lddq, lddk = dqkv.data_ptr(), dqkv.data_ptr() + E * esz, dqkv.data_ptr() + 2 * E * esz, W3, W3
+            dkv = None
+        else:
+            dqkv = torch.empty(qshape, dtype=dtype, device=do.device)
+            dkv = torch.empty(kvshape, dtype=dtype, device=do.device)
+            kp, vp = kvr.data_ptr(), kvr.data_ptr() + E * esz
+            dqp, dkp, dvp, lddq, lddk = dqkv.data_ptr(), dkv.data_ptr(), dkv.data_ptr() + E * esz, E, 2 * E
+        check(lib.psg_attn_bwd(qr.data_ptr(), ldq, kp, ldk, vp, ldk, ptr(o), E, ptr(dor), lddo, ptr(lse), ptr(delta), dqp, lddq, dkp,
+                               lddk, dvp, lddk, B, heads, L, S, d, scale, float(drop_p), int(seed), dtype_code(dtype), stream_ptr()),
+              "psg_attn_bwd")
+        return dqkv, dkv, None, None, None
+
+
+def attention_self(qkv, heads, drop_p=0.0, seed=0):
+    return _AttnFn.apply(qkv, None, heads, drop_p, seed)
+
+
+def attention_cross(q, kv, heads, drop_p=0.0, seed=0):
+    return _AttnFn.apply(q, kv, heads, drop_p, seed)
+
+
+# ---------------------------------------------------------------------------
+# small ops
+# ---------------------------------------------------------------------------
+class _UpsampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, Ho, Wo):
+        lib = _lib_for(x)
+        xr, ldx = _rows(x)
+        B, Hi, Wi, Cc = x.shape
+        y = torch.empty((B, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
+        check(lib.psg_upsample_bilinear_fwd(ptr(xr), ldx, ptr(y), Cc, B, Hi, Wi, Ho, Wo, Cc, dtype_code(x.dtype), stream_ptr()),
+              "psg_upsample_bilinear_fwd")
+        ctx.meta = (B, Hi, Wi, Ho, Wo, Cc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, Hi, Wi, Ho, Wo, Cc = ctx.meta
+        lib = _lib_for(dy)
+        dyr, lddy = _rows(dy)
+        dx = torch.empty((B, Hi, Wi, Cc), dtype=dy.dtype, device=dy.device)
+        check(lib.psg_upsample_bilinear_bwd(ptr(dyr), lddy, ptr(dx), Cc, B, Hi, Wi, Ho, Wo, Cc, dtype_code(dy.dtype), stream_ptr()),
+              "psg_upsample_bilinear_bwd")
+        return dx, None, None
+
+
+def upsample_bilinear(x, size):
+    """nn.Upsample(size, mode='bilinear', align_corners=False) — unet.py:365,375,385."""
+    return _UpsampleFn.apply(x, int(size[0]), int(size[1]))
+
+
+class _ToNCHWFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        lib = _lib_for(x)
+        xr, ldx = _rows(x)
+        B, H, W, Cc = x.shape
+        y = torch.empty((B, Cc, H, W), dtype=torch.float32, device=x.device)
+        check(lib.psg_nhwc_to_nchw(ptr(xr), ldx, ptr(y), B, Cc, H * W, dtype_code(x.dtype), stream_ptr()), "psg_nhwc_to_nchw")
+        ctx.meta = (B, H, W, Cc, x.dtype)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, Cc, dtype = ctx.meta
+        lib = _lib_for(dy)
+        dyc = dy.contiguous().float()
+        dx = torch.empty((B, H, W, Cc), dtype=dtype, device=dy.device)
+        check(lib.psg_nchw_to_nhwc(ptr(dyc), ptr(dx), Cc, B, Cc, H * W, dtype_code(dtype), stream_ptr()), "psg_nchw_to_nhwc")
+        return dx
+
+
+def nhwc_to_nchw(x):
+    """channels-last compute dtype -> the reference's NCHW fp32 boundary layout (differentiable)."""
+    return _ToNCHWFn.apply(x)
+
+
+def nchw_to_nhwc(x, dtype):
+    """[B,C,H,W] fp32 -> [B,H,W,C] compute dtype (network input; no gradient)."""
+    lib = _lib_for(x)
+    xc = x.detach().contiguous().float()
+    B, Cc, H, W = xc.shape
+    y = torch.empty((B, H, W, Cc), dtype=dtype, device=x.device)
+    check(lib.psg_nchw_to_nhwc(ptr(xc), ptr(y), Cc, B, Cc, H * W, dtype_code(dtype), stream_ptr()), "psg_nchw_to_nhwc")
+    return y
+
+
+def text_pool(text, dtype):
+    """AdaptiveAvgPool1d(1) over tokens (unet.py:445) + compute-dtype copy of the tokens."""
+    lib = _lib_for(text)
+    tc = text.detach().contiguous().float()
+    B, S, D = tc.shape
+    pooled = torch.empty((B, D), dtype=dtype, device=text.device)
+    cast = torch.empty((B, S, D), dtype=dtype, device=text.device)
+    check(lib.psg_text_pool(ptr(tc), ptr(pooled), D, ptr(cast), B, S, D, dtype_code(dtype), stream_ptr()), "psg_text_pool")
+    return pooled, cast
+
+
+def timestep_sinusoid(t, coeff, dtype):
+    """cat[sin(t*coeff), cos(t*coeff)] (unet.py:47-50)."""
+    lib = _lib_for(coeff)
+    tt = t.detach().to(device=coeff.device, dtype=torch.int64).contiguous()
+    B, half = tt.shape[0], coeff.shape[0]
+    out = torch.empty((B, 2 * half), dtype=dtype, device=coeff.device)
+    check(lib.psg_timestep_sinusoid(ptr(tt), ptr(coeff.detach().float().contiguous()), ptr(out), 2 * half, B, half, dtype_code(dtype),
+                                    stream_ptr()), "psg_timestep_sinusoid")
+    return out

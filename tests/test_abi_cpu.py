@@ -1,0 +1,98 @@
+"""CPU suite: the C-ABI library builds for gfx950, loads, and exports every symbol include/psg_hip.h
+declares; argument validation returns error codes (no compute is launched without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from pokemon_sprite_generator_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__ as ge
+        ge.build()
+    return _lib.load()
+
+
+def _declared_symbols():
+    txt = open(os.path.join(ROOT, "include", "psg_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(psg_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from pokemon_sprite_generator_amd import _lib
+    names = _declared_symbols()
+    assert len(names) >= 30
+    for n in names:
+        assert hasattr(lib, n), f"libpsg_hip.so does not export {n}"
+        assert n in _lib.SIGNATURES, f"{n} declared in the header but not bound in _lib.SIGNATURES"
+    for n in _lib.SIGNATURES:
+        assert n in names, f"{n} bound but not declared in include/psg_hip.h"
+    assert lib.psg_version() >= 100
+
+
+def test_struct_layouts_match_header():
+    """Compile the header with gcc and compare sizeof/offsetof with the ctypes mirrors."""
+    import subprocess
+    import tempfile
+    from pokemon_sprite_generator_amd._lib import ConvDesc, WgradDesc
+    fields_c = [f for f, _ in ConvDesc._fields_]
+    fields_w = [f for f, _ in WgradDesc._fields_]
+    prog = '#include <stdio.h>\n#include <stddef.h>\n#include "psg_hip.h"\nint main(void){\n'
+    prog += 'printf("%zu\\n", sizeof(psg_conv_desc));\n' + "".join(f'printf("%zu\\n", offsetof(psg_conv_desc, {f}));\n' for f in fields_c)
+    prog += 'printf("%zu\\n", sizeof(psg_wgrad_desc));\n' + "".join(f'printf("%zu\\n", offsetof(psg_wgrad_desc, {f}));\n' for f in fields_w)
+    prog += "return 0;}\n"
+    with tempfile.TemporaryDirectory() as td:
+        src, exe = os.path.join(td, "abi.c"), os.path.join(td, "abi")
+        open(src, "w").write(prog)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", exe])
+        vals = [int(v) for v in subprocess.check_output([exe]).split()]
+    want = [C.sizeof(ConvDesc)] + [getattr(ConvDesc, f).offset for f in fields_c]
+    want += [C.sizeof(WgradDesc)] + [getattr(WgradDesc, f).offset for f in fields_w]
+    assert vals == want
+
+
+def test_argument_validation_without_gpu(lib):
+    """Bad arguments are rejected on the host before any launch: error code + message."""
+    from pokemon_sprite_generator_amd._lib import ConvDesc, WgradDesc
+    d = ConvDesc()
+    assert lib.psg_conv_fwd(C.byref(d), None) < 0
+    assert b"null" in lib.psg_last_error()
+    d.x = d.w = d.y = 0x1000
+    d.dtype = 7
+    assert lib.psg_conv_fwd(C.byref(d), None) == -2                           # PSG_ERR_DTYPE
+    d.dtype = 1
+    d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout = 2, 7, 7, 12, 7, 7, 64       # Cin not a multiple of 8 for bf16
+    d.ksize, d.stride, d.pad = 3, 1, 1
+    d.ldx, d.ldy = 12, 64
+    assert lib.psg_conv_fwd(C.byref(d), None) == -1                           # PSG_ERR_SHAPE
+    assert b"Cin" in lib.psg_last_error()
+    d.Cin, d.ldx, d.Ho = 16, 16, 9                                            # inconsistent geometry
+    assert lib.psg_conv_fwd(C.byref(d), None) == -1
+    w = WgradDesc()
+    assert lib.psg_conv_wgrad_workspace_bytes(C.byref(w)) == -1
+    assert lib.psg_groupnorm_fwd(None, 0, None, 0, None, None, None, None, 1, 1, 32, 32, 1e-5, 0, 0, None) == -6
+    assert lib.psg_kpad(72, 1) == 128 and lib.psg_kpad(72, 0) == 96 and lib.psg_kpad(2880, 1) == 2880
+    assert lib.psg_attn_fwd(0x10, 8, 0x10, 8, 0x10, 8, 0x10, 8, 0x10, 1, 1, 4, 4, 6, 1.0, 0.0, 0, 0, None) == -1   # d % 4
+
+
+def test_product_has_no_cpu_fallback():
+    """Ops refuse CPU tensors loudly instead of rerouting to an eager/oracle path."""
+    import pokemon_sprite_generator_amd as psg
+    from pokemon_sprite_generator_amd import ops
+    with pytest.raises(psg.PsgError):
+        ops.group_norm(torch.zeros(1, 2, 2, 32), torch.ones(32), torch.zeros(32), 32)
+    with pytest.raises(psg.PsgError):
+        psg.NoiseScheduler().add_noise(torch.zeros(1, 8, 2, 2), torch.zeros(1, 8, 2, 2), torch.zeros(1, dtype=torch.long))
+    src = ""
+    pkg = os.path.join(ROOT, "pokemon_sprite_generator_amd")
+    for f in os.listdir(pkg):
+        if f.endswith(".py"):
+            src += open(os.path.join(pkg, f)).read()
+    assert "import oracle" not in src and "from oracle" not in src, "the product must never import the oracle"

@@ -1,0 +1,402 @@
+"""-m gpu: every HIP kernel, through the C ABI, against the CPU oracle / torch fp32 reference
+on the same seeded inputs.  Bit-exact for index/table work, tolerance stated per test for fp."""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import unet_oracle as O
+from tests.util import TOL, from_cl, h, maxrel, rel_l2, to_cl
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _q(x, dtype):
+    """Round an fp32 CPU tensor to the compute dtype (so the reference sees the same inputs)."""
+    return x.to(dtype).float()
+
+
+@pytest.fixture(scope="module")
+def psg():
+    import pokemon_sprite_generator_amd as m
+    from pokemon_sprite_generator_amd import _lib
+    _lib.init(0)
+    return m
+
+
+# ---------------------------------------------------------------- a-2 add_noise (bit-exact)
+def test_noise_add_bit_exact(psg, golden):
+    g = golden("add_noise.npz")
+    x0 = torch.clamp(h((6, 8, 9, 9), "an.x0", 3.5, seed=1234), -3.0, 3.0)
+    nz = h((6, 8, 9, 9), "an.noise", 2.0, seed=1234)
+    t = torch.from_numpy(g["t"])
+    sch = psg.NoiseScheduler()
+    out = sch.add_noise(x0.to(DEV), nz.to(DEV), t.to(DEV)).cpu()
+    assert np.array_equal(out.numpy(), g["out"]), "add_noise differs from the reference fixture bit-for-bit"
+    assert torch.equal(out, O.add_noise(x0, nz, t, O.cosine_clipped_tables()))
+    # fused clamp (trainer :363) on un-clamped input gives the same bits
+    raw = h((6, 8, 9, 9), "an.x0", 3.5, seed=1234)
+    out2 = sch.add_noise(raw.to(DEV), nz.to(DEV), t.to(DEV), clamp=True).cpu()
+    assert np.array_equal(out2.numpy(), g["out"])
+    # NaN/Inf fallback (:61-63), decided on the device
+    bad = nz.clone()
+    bad[2, 3, 4, 5] = float("inf")
+    out3 = sch.add_noise(x0.to(DEV), bad.to(DEV), t.to(DEV)).cpu()
+    assert np.array_equal(out3.numpy(), g["out_fallback"])
+    assert int(sch.nan_flag(DEV).item()) & 1
+
+
+def test_noise_add_edge_cases(psg):
+    sch = psg.NoiseScheduler()
+    # empty batch
+    e = sch.add_noise(torch.zeros(0, 8, 27, 27, device=DEV), torch.zeros(0, 8, 27, 27, device=DEV), torch.zeros(0, dtype=torch.long, device=DEV))
+    assert e.shape == (0, 8, 27, 27)
+    # out-of-range timestep is flagged (bit 1), not a fault
+    x = torch.ones(2, 8, 3, 3, device=DEV)
+    sch.add_noise(x, x, torch.tensor([5, 1000], device=DEV))
+    assert int(sch.nan_flag(DEV).item()) & 2
+    # full-size batch, every timestep value: lookup exactness at B=1000
+    t = torch.arange(1000)
+    x0, nz = h((1000, 8, 4, 4), "big.x0", 2.0), h((1000, 8, 4, 4), "big.nz", 1.0)
+    got = sch.add_noise(x0.to(DEV), nz.to(DEV), t.to(DEV)).cpu()
+    assert torch.equal(got, O.add_noise(x0, nz, t, O.cosine_clipped_tables()))
+
+
+def test_c_oracle_agrees(psg):
+    """The plain-C oracle (oracle/noise_oracle.c) and the HIP kernel give identical bits."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "oracle")], stdout=subprocess.DEVNULL)
+    lib = C.CDLL(os.path.join(root, "oracle", "libpsg_oracle.so"))
+    x0, nz = h((4, 8, 27, 27), "c.x0", 3.5), h((4, 8, 27, 27), "c.nz", 1.0)
+    t = torch.tensor([0, 500, 999, 37], dtype=torch.int64)
+    tb = O.cosine_clipped_tables()
+    out = torch.empty_like(x0)
+    f32p = lambda a: a.numpy().ctypes.data_as(C.c_void_p)
+    lib.oracle_noise_add_f32(f32p(x0), f32p(nz), t.numpy().ctypes.data_as(C.c_void_p), f32p(tb["sqrt_alphas_cumprod"]),
+                             f32p(tb["sqrt_one_minus_alphas_cumprod"]), f32p(out), None, C.c_int64(4), C.c_int64(8 * 27 * 27), 1)
+    got = psg.NoiseScheduler().add_noise(x0.to(DEV), nz.to(DEV), t.to(DEV), clamp=True).cpu()
+    assert torch.equal(got, out)
+
+
+# ---------------------------------------------------------------- a-8 SmoothL1 / a-9 ddpm update
+def test_smooth_l1(psg):
+    unet = torch.nn.Linear(2, 2)  # placeholder owner of nothing; use the stepper's fused loss via a tiny UNetBlock-free path
+    from pokemon_sprite_generator_amd import _lib
+    lib = _lib.init(0)
+    pred, tgt = h((4, 8, 27, 27), "sl.p", 1.0), h((4, 8, 27, 27), "sl.t", 1.0)
+    pred[0, 0, 0, :8] = tgt[0, 0, 0, :8] + torch.tensor([0.05, -0.05, 0.1, -0.1, 0.0999, 0.2, -3.0, 0.0])   # both branches + boundary
+    p = pred.clone().requires_grad_(True)
+    ref = O.smooth_l1(p, tgt, 0.1)
+    ref.backward()
+    pd, td = pred.to(DEV), tgt.to(DEV)
+    grad, loss = torch.empty_like(pd), torch.zeros(1, device=DEV)
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    ws = torch.empty(lib.psg_reduce_workspace_bytes(), dtype=torch.uint8, device=DEV)
+    _lib.check(lib.psg_smooth_l1_f32(_lib.ptr(pd), _lib.ptr(td), _lib.ptr(grad), _lib.ptr(loss), _lib.ptr(flag), 0.1, 1.0, pd.numel(),
+                                     _lib.ptr(ws), _lib.stream_ptr()))
+    assert abs(float(loss.item()) - float(ref)) / float(ref) < 1e-5          # fp32 reduction order only
+    assert maxrel(grad.cpu(), p.grad) < 1e-6
+    assert torch.equal(F.smooth_l1_loss(pred, tgt, beta=0.1), ref.detach()) or abs(float(F.smooth_l1_loss(pred, tgt, beta=0.1)) - float(ref)) < 1e-6
+    assert int(flag.item()) == 0
+
+
+def test_ddpm_update_bit_exact(psg):
+    from pokemon_sprite_generator_amd import _lib
+    lib = _lib.init(0)
+    sch = psg.NoiseScheduler()
+    tb = O.cosine_clipped_tables()
+    c1, c2, sg = sch.step_tables(DEV)
+    for t in (999, 950, 500, 50, 1, 0):
+        x, eps, z = h((3, 8, 27, 27), f"dd.x{t}", 2.0), h((3, 8, 27, 27), f"dd.e{t}", 1.0), h((3, 8, 27, 27), f"dd.z{t}", 1.0)
+        a, b, s = O.ddpm_step_coeffs(tb, t)
+        ref = a * (x - b * eps)
+        if t > 0:
+            ref = ref + s * z
+        xd = x.to(DEV).clone()
+        td = torch.tensor([t], dtype=torch.int32, device=DEV)
+        _lib.check(lib.psg_ddpm_update_f32(_lib.ptr(xd), _lib.ptr(eps.to(DEV)), _lib.ptr(z.to(DEV)), _lib.ptr(c1), _lib.ptr(c2), _lib.ptr(sg),
+                                           _lib.ptr(td), xd.numel(), _lib.stream_ptr()))
+        assert torch.equal(xd.cpu(), ref), f"ddpm update differs at t={t}"
+
+
+# ---------------------------------------------------------------- small ops
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_layout_pool_sinusoid(psg, dtype):
+    from pokemon_sprite_generator_amd import ops
+    x = h((3, 8, 27, 27), "lay.x", 2.0)
+    cl = ops.nchw_to_nhwc(x.to(DEV), dtype)
+    assert cl.shape == (3, 27, 27, 8)
+    assert torch.equal(cl.float().cpu(), to_cl(x, dtype).float())
+    back = ops.nhwc_to_nchw(cl)
+    assert torch.equal(back.cpu(), _q(x, dtype))
+    text = h((3, 32, 256), "lay.t", 1.5)
+    pooled, cast = ops.text_pool(text.to(DEV), dtype)
+    assert maxrel(pooled.float().cpu(), text.mean(dim=1)) < TOL[dtype] * 0.5
+    assert torch.equal(cast.float().cpu(), _q(text, dtype))
+    t = torch.tensor([0, 1, 500, 999, 37, 250])
+    coeff = torch.exp(torch.arange(64) * -(math.log(10000) / 63))
+    e = t.float().unsqueeze(-1) * coeff.unsqueeze(0)
+    ref = torch.cat([torch.sin(e), torch.cos(e)], dim=-1)
+    got = ops.timestep_sinusoid(t.to(DEV), coeff.to(DEV), dtype).float().cpu()
+    assert (got - ref).abs().max() < (2e-6 if dtype == torch.float32 else 4e-3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("hi,ho", [(4, 7), (7, 14), (14, 27)])
+def test_upsample(psg, dtype, hi, ho):
+    from pokemon_sprite_generator_amd import ops
+    x = _q(h((2, 64, hi, hi), f"up.x{hi}", 1.5), dtype).requires_grad_(True)
+    g = _q(h((2, 64, ho, ho), f"up.g{hi}", 1.0), dtype)
+    ref = F.interpolate(x, size=(ho, ho), mode="bilinear", align_corners=False)
+    ref.backward(g)
+    xd = to_cl(x.detach(), dtype).to(DEV).requires_grad_(True)
+    y = ops.upsample_bilinear(xd, (ho, ho))
+    y.backward(to_cl(g, dtype).to(DEV))
+    assert maxrel(from_cl(y.cpu()), ref) < TOL[dtype]
+    assert maxrel(from_cl(xd.grad.cpu()), x.grad) < TOL[dtype]
+
+
+# ---------------------------------------------------------------- GroupNorm (+SiLU)
+GN_CASES = [  # B, HW (as H), C, eps, silu
+    (2, 7, 64, 1e-5, True), (2, 27, 320, 1e-5, True), (1, 14, 1280, 1e-5, True), (2, 4, 2560, 1e-5, True),
+    (2, 27, 640, 1e-5, True), (3, 7, 1280, 1e-6, False), (2, 5, 128, 1e-6, False),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,C,eps,silu", GN_CASES)
+def test_groupnorm(psg, dtype, B, H, C, eps, silu):
+    from pokemon_sprite_generator_amd import ops
+    G = 32
+    x = _q(h((B, C, H, H), f"gn.x{C}", 1.3) + 0.4, dtype).requires_grad_(True)
+    gamma = (1.0 + h((C,), f"gn.g{C}", 0.3)).requires_grad_(True)
+    beta = h((C,), f"gn.b{C}", 0.2).requires_grad_(True)
+    gy = _q(h((B, C, H, H), f"gn.gy{C}", 1.0), dtype)
+    ref = F.group_norm(x, G, gamma, beta, eps)
+    if silu:
+        ref = F.silu(ref)
+    ref.backward(gy)
+    xd = to_cl(x.detach(), dtype).to(DEV).requires_grad_(True)
+    gd, bd = gamma.detach().to(DEV).requires_grad_(True), beta.detach().to(DEV).requires_grad_(True)
+    y = ops.group_norm(xd, gd, bd, G, eps, silu)
+    y.backward(to_cl(gy, dtype).to(DEV))
+    tol = TOL[dtype]
+    assert maxrel(from_cl(y.cpu()), ref) < tol
+    assert maxrel(from_cl(xd.grad.cpu()), x.grad) < tol * 2
+    assert maxrel(gd.grad.cpu(), gamma.grad) < tol * 2
+    assert maxrel(bd.grad.cpu(), beta.grad) < tol * 2
+
+
+# ---------------------------------------------------------------- conv / linear
+CONV_CASES = [  # B, H, Cin, Cout, ks, stride
+    (2, 7, 64, 128, 3, 1), (3, 5, 64, 64, 3, 1), (2, 9, 64, 64, 3, 2), (2, 14, 128, 64, 3, 2), (2, 27, 64, 64, 3, 2),
+    (2, 4, 128, 64, 1, 1), (2, 27, 8, 320, 3, 1), (2, 27, 320, 8, 3, 1), (1, 4, 2560, 128, 3, 1), (5, 7, 192, 320, 3, 1),
+    (1, 27, 320, 320, 3, 1),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,Cin,Cout,ks,stride", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(psg, dtype, B, H, Cin, Cout, ks, stride):
+    from pokemon_sprite_generator_amd import ops
+    pad = 1 if ks == 3 else 0
+    name = f"cv{B}.{H}.{Cin}.{Cout}.{ks}.{stride}"
+    x = _q(h((B, Cin, H, H), name + "x", 1.2), dtype).requires_grad_(True)
+    w = _q(h((Cout, Cin, ks, ks), name + "w", math.sqrt(3.0 / (Cin * ks * ks))), dtype).requires_grad_(True)
+    b = h((Cout,), name + "b", 0.2).requires_grad_(True)
+    ref = F.conv2d(x, w, b, stride=stride, padding=pad)
+    Ho = ref.shape[-1]
+    ra = _q(h((B, Cout), name + "ra", 0.5), dtype).requires_grad_(True)
+    res = _q(h((B, Cout, Ho, Ho), name + "res", 1.0), dtype).requires_grad_(True)
+    ref = ref + ra[:, :, None, None] + res
+    gy = _q(h(tuple(ref.shape), name + "gy", 1.0), dtype)
+    ref.backward(gy)
+    xd = to_cl(x.detach(), dtype).to(DEV).requires_grad_(True)
+    wd = w.detach().to(DEV).requires_grad_(True)
+    bd = b.detach().to(DEV).requires_grad_(True)
+    rad = ra.detach().to(dtype).to(DEV).requires_grad_(True)
+    resd = to_cl(res.detach(), dtype).to(DEV).requires_grad_(True)
+    y = ops.conv2d(xd, wd, bd, stride=stride, rowadd=rad, residual=resd)
+    y.backward(to_cl(gy, dtype).to(DEV))
+    tol = TOL[dtype]
+    assert maxrel(from_cl(y.cpu()), ref) < tol, "forward"
+    assert maxrel(from_cl(xd.grad.cpu()), x.grad) < tol, "dgrad"
+    assert maxrel(wd.grad.cpu(), w.grad) < tol, "wgrad"
+    assert maxrel(bd.grad.cpu(), b.grad) < tol, "dbias"
+    assert maxrel(rad.grad.float().cpu(), ra.grad) < tol, "d rowadd"
+    assert maxrel(from_cl(resd.grad.cpu()), res.grad) < tol, "d residual"
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("act", ["none", "silu", "gelu"])
+def test_linear_epilogue(psg, dtype, act):
+    from pokemon_sprite_generator_amd import ops
+    M, K, N = 150, 256, 192
+    x = _q(h((3, 50, K), "li.x" + act, 1.0), dtype).requires_grad_(True)
+    w = _q(h((N, K), "li.w" + act, math.sqrt(3.0 / K)), dtype).requires_grad_(True)
+    b = h((N,), "li.b" + act, 0.3).requires_grad_(True)
+    res = _q(h((3, 50, N), "li.r" + act, 1.0), dtype).requires_grad_(True)
+    u = F.linear(x, w, b)
+    a = {"none": u, "silu": F.silu(u), "gelu": F.gelu(u)}[act]
+    ref = res + 0.7 * a
+    gy = _q(h((3, 50, N), "li.g" + act, 1.0), dtype)
+    ref.backward(gy)
+    code = {"none": ops.ACT_NONE, "silu": ops.ACT_SILU, "gelu": ops.ACT_GELU}[act]
+    xd, wd, bd = x.detach().to(dtype).to(DEV).requires_grad_(True), w.detach().to(DEV).requires_grad_(True), b.detach().to(DEV).requires_grad_(True)
+    rd = res.detach().to(dtype).to(DEV).requires_grad_(True)
+    y = ops.linear(xd, wd, bd, residual=rd, act=code, alpha=0.7)
+    y.backward(gy.to(dtype).to(DEV))
+    tol = TOL[dtype]
+    assert maxrel(y.float().cpu(), ref) < tol
+    assert maxrel(xd.grad.float().cpu(), x.grad) < tol * 2
+    assert maxrel(wd.grad.cpu(), w.grad) < tol * 2
+    assert maxrel(bd.grad.cpu(), b.grad) < tol * 2
+    assert maxrel(rd.grad.float().cpu(), res.grad) < tol
+
+
+def test_linear_dropout_consistent(psg):
+    """Dropout mask: right keep-rate, and the SAME mask in forward and backward."""
+    from pokemon_sprite_generator_amd import ops
+    p = 0.3
+    x = h((64, 128), "dr.x", 1.0).to(DEV).requires_grad_(True)
+    w = h((256, 128), "dr.w", 0.2).to(DEV).requires_grad_(True)
+    y = ops.linear(x, w, None, drop_p=p, seed=77)
+    keep = (y != 0).float()
+    rate = float(keep.mean())
+    assert abs(rate - (1 - p)) < 0.02, rate
+    ref = (x.detach() @ w.detach().t()) * keep / (1 - p)
+    assert maxrel(y, ref) < 1e-4
+    g = h((64, 256), "dr.g", 1.0).to(DEV)
+    y.backward(g)
+    gm = g * keep / (1 - p)
+    assert maxrel(x.grad, gm @ w.detach()) < 1e-4
+    assert maxrel(w.grad, gm.t() @ x.detach()) < 1e-4
+    y2 = ops.linear(x.detach(), w.detach(), None, drop_p=p, seed=78)
+    assert not torch.equal((y2 != 0), (y != 0))
+
+
+def test_conv_linearity_full_size(psg):
+    """Size-independent property at the benchmark shape (B=256, 27x27x320): conv(a*x1 + x2) == a*conv(x1) + conv(x2) (bf16 path)."""
+    from pokemon_sprite_generator_amd import ops
+    torch.manual_seed(0)
+    x1 = torch.randn(256, 27, 27, 320, device=DEV).bfloat16()
+    x2 = torch.randn(256, 27, 27, 320, device=DEV).bfloat16()
+    w = torch.randn(320, 320, 3, 3, device=DEV) * 0.02
+    with torch.no_grad():
+        y1, y2 = ops.conv2d(x1, w), ops.conv2d(x2, w)
+        xs = (2.0 * x1.float() + x2.float()).bfloat16()
+        ys = ops.conv2d(xs, w)
+    err = rel_l2(ys.float(), 2.0 * y1.float() + y2.float())
+    assert err < 2e-2, err
+    # spot-check 64 random output pixels against a CPU fp32 conv of the same bf16 inputs
+    idx = torch.randint(0, 256, (4,)).tolist()
+    ref = F.conv2d(x1[idx].float().cpu().permute(0, 3, 1, 2), w.bfloat16().float().cpu(), padding=1)
+    assert maxrel(from_cl(y1[idx].cpu()), ref) < 2e-2
+
+
+# ---------------------------------------------------------------- attention core
+ATTN_CASES = [  # B, heads, L, S, d, self
+    (2, 8, 16, 16, 16, True), (2, 4, 49, 49, 32, True), (1, 8, 196, 196, 80, True), (2, 8, 16, 32, 160, False),
+    (2, 8, 196, 32, 80, False), (1, 4, 49, 20, 320, False), (1, 8, 49, 32, 160, False),
+]
+
+
+def _attn_ref(q, k, v, heads):
+    B, L, E = q.shape
+    S, d = k.shape[1], E // heads
+    qh = q.view(B, L, heads, d).transpose(1, 2) * math.sqrt(1.0 / d)
+    kh = k.view(B, S, heads, d).transpose(1, 2)
+    vh = v.view(B, S, heads, d).transpose(1, 2)
+    p = torch.softmax(qh @ kh.transpose(-2, -1), dim=-1)
+    return (p @ vh).transpose(1, 2).reshape(B, L, E)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,heads,L,S,d,self_mode", ATTN_CASES)
+def test_attention(psg, dtype, B, heads, L, S, d, self_mode):
+    from pokemon_sprite_generator_amd import ops
+    E = heads * d
+    name = f"at{B}.{heads}.{L}.{S}.{d}"
+    if self_mode:
+        qkv = _q(h((B, L, 3 * E), name, 1.0), dtype).requires_grad_(True)
+        ref = _attn_ref(qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:], heads)
+    else:
+        qs = _q(h((B, L, E), name + "q", 1.0), dtype).requires_grad_(True)
+        kv = _q(h((B, S, 2 * E), name + "kv", 1.0), dtype).requires_grad_(True)
+        ref = _attn_ref(qs, kv[..., :E], kv[..., E:], heads)
+    go = _q(h((B, L, E), name + "g", 1.0), dtype)
+    ref.backward(go)
+    tol = TOL[dtype]
+    if self_mode:
+        qd = qkv.detach().to(dtype).to(DEV).requires_grad_(True)
+        o = ops.attention_self(qd, heads)
+        o.backward(go.to(dtype).to(DEV))
+        assert maxrel(o.float().cpu(), ref) < tol
+        assert maxrel(qd.grad.float().cpu(), qkv.grad) < tol * 2
+    else:
+        qd = qs.detach().to(dtype).to(DEV).requires_grad_(True)
+        kd = kv.detach().to(dtype).to(DEV).requires_grad_(True)
+        o = ops.attention_cross(qd, kd, heads)
+        o.backward(go.to(dtype).to(DEV))
+        assert maxrel(o.float().cpu(), ref) < tol
+        assert maxrel(qd.grad.float().cpu(), qs.grad) < tol * 2
+        assert maxrel(kd.grad.float().cpu(), kv.grad) < tol * 2
+
+
+def test_attention_softmax_spike(psg):
+    """A forced large logit (one key aligned with one query) must not overflow: softmax is max-subtracted."""
+    from pokemon_sprite_generator_amd import ops
+    B, heads, L, d = 1, 2, 32, 16
+    E = heads * d
+    qkv = h((B, L, 3 * E), "spike", 1.0)
+    qkv[0, 3, :E] = 60.0
+    qkv[0, 5, E:2 * E] = 60.0
+    ref = _attn_ref(qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:], heads)
+    o = ops.attention_self(qkv.to(DEV), heads)
+    assert torch.isfinite(o).all()
+    assert maxrel(o.cpu(), ref) < 1e-3
+
+
+def test_attention_dropout_statistics(psg):
+    from pokemon_sprite_generator_amd import ops
+    B, heads, L, d = 4, 8, 49, 16
+    E = heads * d
+    qkv = torch.zeros(B, L, 3 * E)
+    qkv[..., 2 * E:] = 1.0                      # v = 1 -> o = sum_j drop(P)_j ; E[o] = 1, Var = p/((1-p) L)
+    o = ops.attention_self(qkv.to(DEV), heads, 0.05, 123).cpu()
+    assert abs(float(o.mean()) - 1.0) < 0.01
+    assert 0.5 * 0.05 / (0.95 * L) < float(o.var()) < 2.0 * 0.05 / (0.95 * L)
+
+
+# ---------------------------------------------------------------- optimizer
+def test_sumsq_adamw_clip(psg):
+    from pokemon_sprite_generator_amd import FusedAdamW, GradArena
+    torch.manual_seed(1)
+    shapes = [(320, 64, 3, 3), (1280,), (77, 13), (5,)]
+    ps_ref = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    ps = [torch.nn.Parameter(p.detach().clone().to(DEV)) for p in ps_ref]
+    arena = GradArena(ps)
+    opt_ref = torch.optim.AdamW(ps_ref, lr=3e-4, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01)
+    opt = FusedAdamW(ps, lr=3e-4, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01)
+    for step in range(4):
+        gs = [torch.randn(s) * (3.0 if step % 2 == 0 else 0.01) for s in shapes]
+        arena.zero()
+        for p, pr, g in zip(ps, ps_ref, gs):
+            pr.grad = g.clone()
+            p.grad.copy_(g.to(DEV))
+        total = torch.nn.utils.clip_grad_norm_(ps_ref, max_norm=1.0)
+        nsq = arena.grad_norm_sq()
+        assert abs(float(nsq.sqrt().item()) - float(total)) / float(total) < 1e-5
+        opt_ref.step()
+        opt.step(normsq=nsq, max_norm=1.0)
+        for p, pr in zip(ps, ps_ref):
+            assert maxrel(p.detach().cpu(), pr.detach()) < 2e-6, f"step {step}"
+    sd = opt.state_dict()
+    assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}      # torch.optim.AdamW wire format
