@@ -125,8 +125,8 @@ def _wgrad_launch(lib, dtype, x, ldx, dy, lddy, dw, geom, Cin, Cout, accumulate=
     check(lib.psg_conv_wgrad(C.byref(d), stream_ptr()), "psg_conv_wgrad")
 
 
-def _colsum(lib, a, lda, R, groups, cols, dtype, out_dtype):
-    out = torch.empty((groups, cols) if groups > 1 else (cols,), dtype=out_dtype, device=a.device)
+def _colsum(lib, a, lda, R, groups, cols, dtype, out_dtype, keep2d=False):
+    out = torch.empty((groups, cols) if keep2d or groups > 1 else (cols,), dtype=out_dtype, device=a.device)
     need = lib.psg_colsum_workspace_bytes(R, groups, cols)
     ws = _lib.workspace(need, a.device)
     check(lib.psg_colsum(ptr(a), lda, ptr(out), cols, R, groups, cols, dtype_code(dtype), dtype_code(out_dtype), 0,
@@ -158,7 +158,7 @@ class _ConvFn(torch.autograd.Function):
             out_shape = tuple(x.shape[:-1]) + (Cout,)
         geom = (B, Hi, Wi, Ho, Wo, ks, stride, pad)
         need_dx = ctx.needs_input_grad[0]
-        wf, wd = WeightCache.get(weight, dtype, need_dx and torch.is_grad_enabled())
+        wf, wd = WeightCache.get(weight, dtype, need_dx)
         y = torch.empty(out_shape, dtype=dtype, device=x.device)
         has_epi = (act != ACT_NONE)
         any_grad = any(ctx.needs_input_grad)
@@ -206,7 +206,7 @@ class _ConvFn(torch.autograd.Function):
         if has_bias and ctx.needs_input_grad[2]:
             db = _colsum(lib, g, ldg, M, 1, Cout, dtype, torch.float32)
         if has_ra and ctx.needs_input_grad[3]:
-            dra = _colsum(lib, g, ldg, Ho * Wo, B, Cout, dtype, dtype)
+            dra = _colsum(lib, g, ldg, Ho * Wo, B, Cout, dtype, dtype, keep2d=True)
         return dx, dw, db, dra, d_res, None, None, None, None, None
 
 
@@ -229,7 +229,7 @@ class _CrossInProjFn(torch.autograd.Function):
         lib = _lib_for(xn)
         dtype = xn.dtype
         E = weight.shape[1]
-        wf, wd = WeightCache.get(weight, dtype, torch.is_grad_enabled())
+        wf, wd = WeightCache.get(weight, dtype, ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
         xr, ldx = _rows(xn)
         tr, ldt = _rows(tp)
         Mq, Mk = xn.numel() // E, tp.numel() // E

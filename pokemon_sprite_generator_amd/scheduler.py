@@ -10,6 +10,14 @@ import torch
 from . import _lib
 from ._lib import check, ptr, stream_ptr
 
+def _canon(device):
+    """torch.device with an explicit index for GPUs ('cuda' -> 'cuda:<current>')."""
+    device = torch.device(device)
+    if device.type == "cuda" and device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
+
+
 _TABLES = ("betas", "alphas", "alphas_cumprod", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod")
 
 
@@ -35,7 +43,7 @@ class NoiseScheduler:
 
     def to(self, device):
         """Move the tables to `device` (idempotent, unlike the reference's per-call re-upload)."""
-        device = torch.device(device)
+        device = _canon(device)
         if self.betas.device != device:
             for n in _TABLES:
                 setattr(self, n, getattr(self, n).to(device, dtype=torch.float32))
@@ -45,7 +53,8 @@ class NoiseScheduler:
 
     # -- device-side NaN/Inf flag (bit 0: non-finite output, bit 1: timestep out of range) ------------
     def nan_flag(self, device):
-        if self._flag is None or self._flag.device != torch.device(device):
+        device = _canon(device)
+        if self._flag is None or self._flag.device != device:
             self._flag = torch.zeros(1, dtype=torch.int32, device=device)
         return self._flag
 
@@ -79,7 +88,8 @@ class NoiseScheduler:
     # -- per-timestep sampler scalars (ddpm_sample :543-562), same torch ops as the reference -----------
     def step_tables(self, device):
         """c1 = 1/sqrt(alpha_t), c2 = beta_t/sqrt(1-abar_t), sigma = sqrt(beta_t) for every t (fp32 [T])."""
-        if self._step_tables is None or self._step_tables[0].device != torch.device(device):
+        device = _canon(device)
+        if self._step_tables is None or self._step_tables[0].device != device:
             a, ac, b = self.alphas.cpu(), self.alphas_cumprod.cpu(), self.betas.cpu()
             c1 = 1.0 / torch.sqrt(a)
             c2 = b / torch.sqrt(1 - ac)

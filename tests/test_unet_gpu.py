@@ -26,6 +26,15 @@ def psg():
     return m
 
 
+def _fixture_scheduler(psg, golden):
+    """Scheduler with the fixture's tables (the reference's tables are host-CPU dependent in the last bit)."""
+    g = golden("schedule.npz")
+    s = psg.NoiseScheduler()
+    for n in ("betas", "alphas", "alphas_cumprod", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod"):
+        setattr(s, n, torch.from_numpy(g["cos_" + n]).clone())
+    return s
+
+
 def _fill(module, prefix, mode="stress"):
     shapes = {prefix + k: tuple(v.shape) for k, v in module.state_dict().items()}
     sd = hashgen.fill_unet_state(shapes, cases.WEIGHT_SEED, mode)
@@ -170,7 +179,7 @@ def test_train_step_golden(psg, golden, full_unets):
     u.set_compute_dtype(torch.float32)
     x, t, text = hashgen.unet_inputs(b, cases.INPUT_SEED, t=ts)
     noise = hashgen.uniform(x.shape, cases.INPUT_SEED, hashgen.name_id("train.noise")) * math.sqrt(3.0)
-    st = psg.DiffusionStepper(u, psg.NoiseScheduler(), lr=0.0, weight_decay=0.0, max_grad_norm=1.0, distributed=False)
+    st = psg.DiffusionStepper(u, _fixture_scheduler(psg, golden), lr=0.0, weight_decay=0.0, max_grad_norm=1.0, distributed=False)
     u.eval()                                           # dropout off, like the fixture
     st.flag.zero_()
     noisy = st.noise_scheduler.add_noise((x * 2.0).to(DEV), noise.to(DEV), t.to(DEV), clamp=True, flag=st.flag)
@@ -215,7 +224,7 @@ def test_sampler_trace_golden(psg, golden, full_unets):
     u, _ = full_unets(mode, heads)
     u.set_compute_dtype(torch.float32)
     _, _, text = hashgen.unet_inputs(n, cases.INPUT_SEED)
-    st = psg.DiffusionStepper(u, psg.NoiseScheduler(), lr=0.0, distributed=False)
+    st = psg.DiffusionStepper(u, _fixture_scheduler(psg, golden), lr=0.0, distributed=False)
 
     def noise_fn(i, shape):
         nm = "sample.xT" if i < 0 else f"sample.z{i}"
