@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py — U-Net train steps/s (per-GPU batch 256, 27x27x8 latents, 32x256 text) on N MI355X.
+
+One "step" = the reference's train-loop body (improved_diffusion_trainer.py:363-413):
+clamp + add_noise -> U-Net forward (train mode, dropout on) -> SmoothL1 -> backward ->
+[RCCL all-reduce of the 640 M gradients] -> global-norm clip -> AdamW, bf16 MFMA compute with
+fp32 master weights / accumulation (BASELINE.json configs[2]); weak scaling (256 samples per
+GPU), value = bs256-steps completed by all ranks per second (= samples/s / 256).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch 256] [--dtype bf16|fp32]
+Multi-GPU: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FWD_BWD_GFLOP_PER_SAMPLE = 232.12      # FlopCounterMode on the reference, 2*MAC
+PEAK_BF16 = 2.5e15                      # dense bf16 MFMA, MI355X_MICROARCH.md
+PEAK_F32 = 157.3e12                     # fp32 matrix (= vector) rate
+KINDS = ["conv_gemm(fwd gather)", "conv_gemm(dgrad gather)", "wgrad", "attention", "groupnorm"]
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The oracle (CPU restatement of the reference path) timed on this host's cores on a bounded
+    sample of the same workload: forward+backward+AdamW of the full-width U-Net at batch 2."""
+    from oracle import unet_oracle as O
+    import pokemon_sprite_generator_amd as psg
+    with torch.device("meta"):
+        shapes = {k: tuple(v.shape) for k, v in psg.UNet().state_dict().items()}
+    g = torch.Generator().manual_seed(0)
+    sd = {}
+    for k, s in shapes.items():
+        if k.endswith("emb_coeff"):
+            sd[k] = torch.exp(torch.arange(s[0]) * -(torch.log(torch.tensor(10000.0)) / (s[0] - 1)))
+        elif k.endswith("weight") and len(s) >= 2:
+            fan = 1
+            for d in s[1:]:
+                fan *= d
+            sd[k] = torch.randn(s, generator=g) * (fan ** -0.5)
+        elif "norm" in k and k.endswith("weight"):
+            sd[k] = torch.ones(s)
+        else:
+            sd[k] = torch.zeros(s)
+    B = 2
+    x = torch.randn(B, 8, 27, 27, generator=g)
+    text = torch.randn(B, 32, 256, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    noise = torch.randn(B, 8, 27, 27, generator=g)
+    tables = O.cosine_clipped_tables()
+    cores = torch.get_num_threads()
+    times = []
+    t_start = time.time()
+    m = {k: torch.zeros_like(v) for k, v in sd.items() if not k.endswith("emb_coeff")}
+    v2 = {k: torch.zeros_like(v) for k, v in m.items()}
+    step = 0
+    while True:
+        t0 = time.time()
+        r = O.train_step_grads(sd, x, text, t, noise, tables, 8)
+        coef = O.clip_coef(r["grad_norm"], 1.0)
+        step += 1
+        for k, gk in r["grads"].items():
+            sd[k], m[k], v2[k] = O.adamw_update(sd[k], gk * coef, m[k], v2[k], step, 1e-4, 0.9, 0.999, 1e-6, 0.01)
+        times.append(time.time() - t0)
+        if time.time() - t_start > seconds_budget or len(times) >= 4:
+            break
+    best = min(times)
+    return {"value": (B / best) / 256.0, "unit": "bs256-steps/s", "cores": cores, "kind": "port",
+            "sample": f"oracle fwd+bwd+clip+AdamW, full-width U-Net, batch {B}, fp32, dropout off; best of {len(times)} ({best:.2f} s/step); "
+                      f"scaled to batch-256 steps", "samples_per_s": B / best}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (metric is quoted at 256)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event roofline leg")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+
+    import pokemon_sprite_generator_amd as psg
+    from pokemon_sprite_generator_amd import _lib
+    lib = _lib.init(local_rank)
+    dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    torch.manual_seed(1234)                      # same initial weights on every rank
+    unet = psg.UNet(latent_dim=8, text_dim=256, time_emb_dim=128, num_heads=8, compute_dtype=dtype).to(dev)
+    stepper = psg.DiffusionStepper(unet, psg.NoiseScheduler(), lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01, eps=1e-6,
+                                   max_grad_norm=1.0, distributed=(world > 1))
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    B = args.batch
+    latents = torch.randn(B, 8, 27, 27, device=dev, generator=gen) * 1.2     # clamp(-3,3) applies inside the step
+    text = torch.randn(B, 32, 256, device=dev, generator=gen)
+
+    def one_step():
+        t = torch.randint(0, 1000, (B,), device=dev, generator=gen)
+        noise = torch.randn(B, 8, 27, 27, device=dev, generator=gen)
+        return stepper.train_step(latents, text, t, noise)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = one_step()
+    barrier()
+    if not args.no_profile and rank == 0:
+        _lib.check(lib.psg_profile_begin(), "psg_profile_begin")
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = None
+    if not args.no_profile and rank == 0:
+        n = len(KINDS)
+        ms, work, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_int64 * n)()
+        _lib.check(lib.psg_profile_end(ms, work, cnt, n), "psg_profile_end")
+        prof = [(KINDS[i], ms[i], work[i], cnt[i]) for i in range(n)]
+    tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    loss, flag = float(out["loss"].item()), int(out["nan_flag"].item())
+
+    if rank == 0:
+        steps_per_s = world * args.steps / elapsed
+        samples_per_s = steps_per_s * B
+        peak = PEAK_BF16 if args.dtype == "bf16" else PEAK_F32
+        res = {
+            "metric": "unet_train_steps_per_sec_bs256", "value": steps_per_s * (B / 256.0), "unit": "bs256-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"full train_step (add_noise+fwd+SmoothL1+bwd+clip+AdamW), U-Net 640M params, per-GPU batch {B}, "
+                                   f"27x27x8 latents, 32x256 text, 8 heads, train mode (dropout 0.05), {args.dtype} MFMA / fp32 master+accum",
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}"},
+            "samples_per_s": samples_per_s,
+            "step_mfma_frac_of_peak": samples_per_s * FWD_BWD_GFLOP_PER_SAMPLE * 1e9 / (peak * world),
+            "final_loss": loss, "nan_flag": flag,
+        }
+        if prof:
+            fam = []
+            for name, ms_k, work_k, cnt_k in prof:
+                if cnt_k == 0:
+                    continue
+                is_bytes = name == "groupnorm"
+                ach = work_k / (ms_k * 1e-3)
+                fam.append({"kernel": name, "launches_per_step": cnt_k / args.steps, "ms_per_step": ms_k / args.steps,
+                            "avg_launch_us": 1e3 * ms_k / cnt_k, "bound": "hbm" if is_bytes else "mfma",
+                            "achieved": ach / (1e9 if is_bytes else 1e12), "unit": "GB/s" if is_bytes else "TFLOP/s",
+                            "peak": 8000.0 if is_bytes else peak / 1e12, "frac": ach / (8e12 if is_bytes else peak)})
+            dom = max(fam, key=lambda f: f["ms_per_step"])
+            res["roofline"] = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
+                               "frac": dom["frac"], "traffic": None, "kernel": dom["kernel"],
+                               "avg_launch_us": dom["avg_launch_us"], "launches_per_step": dom["launches_per_step"],
+                               "ms_per_step": dom["ms_per_step"],
+                               "how": "algorithmic 2*M*N*K FLOPs summed over the family's launches / HIP-event time on the launch stream"}
+            res["kernel_families"] = fam
+        if not args.no_cpu_baseline and world == 1:
+            try:
+                res["cpu_baseline"] = cpu_baseline()
+            except Exception as e:                      # noqa: BLE001
+                res["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

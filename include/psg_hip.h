@@ -237,6 +237,16 @@ int psg_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float
 /* g *= min(1, max_norm/(sqrt(*normsq)+1e-6)) — plain clip for callers that keep torch.optim. */
 int psg_clip_scale_f32(float* g, int64_t n, const float* normsq, float max_norm, psg_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * Measurement hooks (bench.py): between begin and end every launch of the matrix / attention /
+ * GroupNorm kernel families is bracketed by hipEvents on its stream.  end() drains once and
+ * returns, per family k < nkinds (0 conv fwd gather, 1 conv data-gradient gather, 2 wgrad,
+ * 3 attention, 4 GroupNorm): summed kernel milliseconds, summed algorithmic work (FLOPs for
+ * 0-3, bytes for 4) and launch count.  Off by default: no cost on the product path.
+ * ------------------------------------------------------------------------- */
+int psg_profile_begin(void);
+int psg_profile_end(double* ms, double* work, int64_t* launches, int nkinds);
+
 #ifdef __cplusplus
 }
 #endif

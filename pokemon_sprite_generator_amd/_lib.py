@@ -81,6 +81,8 @@ SIGNATURES = {
     "psg_sumsq_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
     "psg_adamw_f32": (c_int, [c_void_p] * 4 + [c_int64] + [c_float] * 5 + [c_int, c_void_p, c_float, c_void_p, c_void_p]),
     "psg_clip_scale_f32": (c_int, [c_void_p, c_int64, c_void_p, c_float, c_void_p]),
+    "psg_profile_begin": (c_int, []),
+    "psg_profile_end": (c_int, [c_void_p, c_void_p, c_void_p, c_int]),
 }
 
 _lib = None

@@ -348,6 +348,7 @@ int psg_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const v
     p.B = B; p.H = heads; p.L = L; p.S = S; p.d = d; p.scale = scale;
     p.drop_thresh = drop_p > 0.f ? drop_thresh(drop_p) : 0u; p.drop_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f; p.seed = seed;
     dim3 grid((L + AT_Q - 1) / AT_Q, B * heads);
+    ProfScope prof(PROF_ATTN, 4.0 * (double)B * heads * L * S * d, (hipStream_t)stream);
     if (dtype == PSG_F32) hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, p);
     PSG_LAUNCH_CHECK("attn_fwd");
@@ -376,6 +377,7 @@ int psg_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const v
     const int64_t rows = (int64_t)B * heads * L;
     const int gdelta = (int)((rows + 3) / 4);
     dim3 gq((L + AT_Q - 1) / AT_Q, B * heads), gkv((S + AT_Q - 1) / AT_Q, B * heads);
+    ProfScope prof(PROF_ATTN, 10.0 * (double)B * heads * L * S * d, s);
     if (dtype == PSG_F32) {
         hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(gdelta), dim3(256), 0, s, p);
         hipLaunchKernelGGL(attn_dq_kernel<float>, gq, dim3(256), l1, s, p);

@@ -233,6 +233,7 @@ static int launch_conv(const ConvP& p, hipStream_t stream) {
     q.mtiles = (p.M + BM - 1) / BM;
     q.ntiles = (p.N + BN - 1) / BN;
     const int grid = q.mtiles * q.ntiles;
+    ProfScope prof(p.transposed ? PROF_CONV_DGRAD : PROF_CONV_FWD, 2.0 * (double)p.M * (double)p.N * (double)p.taps * (double)p.Cin, stream);
     hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN>), dim3(grid), dim3(256), lds, stream, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "conv_gemm launch");

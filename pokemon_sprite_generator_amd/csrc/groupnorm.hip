@@ -219,6 +219,7 @@ int psg_groupnorm_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, const fl
     const int nel = HW * (C / G);
     const size_t esz = dtype == PSG_BF16 ? 2 : 4;
     const size_t lds = nel <= GN_LDS_ELEMS ? (size_t)nel * esz : 0;
+    ProfScope prof(PROF_GN, 2.0 * (double)B * HW * C * (double)esz, (hipStream_t)stream);
     if (dtype == PSG_F32)
         hipLaunchKernelGGL(gn_fwd_kernel<float>, dim3(B * G), dim3(GN_THREADS), lds, (hipStream_t)stream, (const float*)x, ldx,
                            (float*)y, ldy, gamma, beta, mean, rstd, HW, C, G, eps, silu);
@@ -244,6 +245,7 @@ int psg_groupnorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, 
     const bool in_lds = nel <= GN_LDS_ELEMS;
     PSG_REQUIRE(in_lds || dx != dy, PSG_ERR_ARG, "groupnorm_bwd: dx may alias dy only when the slab fits LDS");
     const size_t lds = in_lds ? (size_t)(((nel + 7) & ~7) + nel) * esz : 0;
+    ProfScope prof(PROF_GN, 3.0 * (double)B * HW * C * (double)esz, (hipStream_t)stream);
     if (dtype == PSG_F32)
         hipLaunchKernelGGL(gn_bwd_kernel<float>, dim3(B * G), dim3(GN_THREADS), lds, (hipStream_t)stream, (const float*)dy, lddy,
                            (const float*)x, ldx, gamma, beta, mean, rstd, (float*)dx, lddx, (float*)ws, B, HW, C, G, silu);

@@ -1,0 +1,69 @@
+// Live per-kernel-family timing with HIP events on the launch stream (bench.py's roofline leg).
+// Disabled by default: zero cost on the product path.  When enabled, every launch of a profiled
+// family is bracketed by a hipEventRecord pair on ITS stream; nothing synchronises until
+// psg_profile_end(), which drains the stream once and sums the elapsed times.
+#include <mutex>
+#include <vector>
+
+#include "psg_common.h"
+
+namespace psg {
+
+struct ProfRec { hipEvent_t a, b; int kind; double work; };
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_recs;
+static std::vector<hipEvent_t> g_pool;
+static std::mutex g_prof_mu;
+
+static hipEvent_t take_event() {
+    if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+    hipEvent_t e;
+    if (hipEventCreate(&e) != hipSuccess) return nullptr;
+    return e;
+}
+
+ProfScope::ProfScope(int kind, double work, hipStream_t stream) : idx_(-1), stream_(stream) {
+    if (!g_prof_on) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    ProfRec r{take_event(), take_event(), kind, work};
+    if (!r.a || !r.b) return;
+    hipEventRecord(r.a, stream);
+    g_recs.push_back(r);
+    idx_ = (int)g_recs.size() - 1;
+}
+ProfScope::~ProfScope() {
+    if (idx_ < 0) return;
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    hipEventRecord(g_recs[idx_].b, stream_);
+}
+
+}  // namespace psg
+using namespace psg;
+
+extern "C" {
+
+int psg_profile_begin(void) {
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (auto& r : g_recs) { g_pool.push_back(r.a); g_pool.push_back(r.b); }
+    g_recs.clear();
+    g_prof_on = true;
+    return PSG_OK;
+}
+
+int psg_profile_end(double* ms, double* work, int64_t* launches, int nkinds) {
+    PSG_REQUIRE(ms && work && launches && nkinds > 0, PSG_ERR_ARG, "profile_end: null pointer");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    g_prof_on = false;
+    for (int k = 0; k < nkinds; ++k) { ms[k] = 0; work[k] = 0; launches[k] = 0; }
+    for (auto& r : g_recs) {
+        if (hipEventSynchronize(r.b) != hipSuccess) return hip_fail(hipGetLastError(), "profile_end sync");
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return hip_fail(hipGetLastError(), "profile_end elapsed");
+        if (r.kind >= 0 && r.kind < nkinds) { ms[r.kind] += t; work[r.kind] += r.work; launches[r.kind] += 1; }
+        g_pool.push_back(r.a); g_pool.push_back(r.b);
+    }
+    g_recs.clear();
+    return PSG_OK;
+}
+
+}  // extern "C"

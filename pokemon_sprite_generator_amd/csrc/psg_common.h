@@ -35,6 +35,15 @@ int hip_fail(hipError_t e, const char* what);
         if (!(cond)) return psg::set_error(code, __VA_ARGS__);    \
     } while (0)
 
+// bench-only timing of a kernel family (profile.hip); a no-op unless psg_profile_begin() was called
+enum ProfKind { PROF_CONV_FWD = 0, PROF_CONV_DGRAD = 1, PROF_WGRAD = 2, PROF_ATTN = 3, PROF_GN = 4, PROF_KINDS = 5 };
+struct ProfScope {
+    ProfScope(int kind, double work, hipStream_t stream);
+    ~ProfScope();
+    int idx_;
+    hipStream_t stream_;
+};
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
 

@@ -272,8 +272,11 @@ int psg_conv_wgrad(const psg_wgrad_desc* d, psg_stream_t stream) {
     p.inv_HoWo = 1.0f / (float)(d->Ho * d->Wo); p.inv_Wo = 1.0f / (float)d->Wo;
     const int grid = p.rtiles * p.qtiles * p.splits;
     hipStream_t s = (hipStream_t)stream;
-    if (d->dtype == PSG_BF16) hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3(grid), dim3(256), 4 * 64 * 320, s, p);
-    else hipLaunchKernelGGL(wgrad_kernel<float>, dim3(grid), dim3(256), 4 * 32 * 512, s, p);
+    {
+        ProfScope prof(PROF_WGRAD, 2.0 * (double)p.M * (double)p.Cout * (double)p.Q, s);
+        if (d->dtype == PSG_BF16) hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3(grid), dim3(256), 4 * 64 * 320, s, p);
+        else hipLaunchKernelGGL(wgrad_kernel<float>, dim3(grid), dim3(256), 4 * 32 * 512, s, p);
+    }
     PSG_LAUNCH_CHECK("wgrad");
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(d->Cout, (d->Cin + 255) / 256), dim3(256), 0, s, (const float*)d->ws, d->dw,
                        d->Cout, d->Cin, p.taps, p.splits, d->accumulate);
