@@ -319,12 +319,39 @@ static int attn_check(const char* who, int B, int heads, int L, int S, int d, in
     return PSG_OK;
 }
 
+// attention_mfma.hip (bf16 matrix-core path)
+struct AttnMP {
+    const bf16_t *q, *k, *v, *o, *dout;
+    bf16_t *out, *dq, *dk, *dv;
+    float* lse; const float* delta;
+    int64_t ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+    int B, H, L, S, d;
+    float scale;
+    uint32_t drop_thresh; float drop_scale; uint64_t seed;
+};
+int attn_mfma_applicable(int L, int S, int d, int dtype, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo);
+int attn_mfma_init_attrs();
+int attn_mfma_fwd(const AttnMP& p, hipStream_t s);
+int attn_mfma_bwd(const AttnMP& p, hipStream_t s);
+
+static AttnMP to_mfma(const AttnP& a) {
+    AttnMP m;
+    m.q = (const bf16_t*)a.q; m.k = (const bf16_t*)a.k; m.v = (const bf16_t*)a.v; m.o = (const bf16_t*)a.o; m.dout = (const bf16_t*)a.dout;
+    m.out = (bf16_t*)a.out; m.dq = (bf16_t*)a.dq; m.dk = (bf16_t*)a.dk; m.dv = (bf16_t*)a.dv;
+    m.lse = a.lse; m.delta = a.delta;
+    m.ldq = a.ldq; m.ldk = a.ldk; m.ldv = a.ldv; m.ldo = a.ldo; m.lddo = a.lddo; m.lddq = a.lddq; m.lddk = a.lddk; m.lddv = a.lddv;
+    m.B = a.B; m.H = a.H; m.L = a.L; m.S = a.S; m.d = a.d; m.scale = a.scale;
+    m.drop_thresh = a.drop_thresh; m.drop_scale = a.drop_scale; m.seed = a.seed;
+    return m;
+}
+
 }  // namespace psg
 using namespace psg;
 
 extern "C" {
 
 int psg_attn_init_attrs(void) {
+    { int rc = attn_mfma_init_attrs(); if (rc) return rc; }
     const int big = 150 * 1024;
 #define SET_LDS(K) PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, big))
     SET_LDS(attn_fwd_kernel<float>); SET_LDS(attn_fwd_kernel<bf16_t>);
@@ -349,6 +376,8 @@ int psg_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const v
     p.drop_thresh = drop_p > 0.f ? drop_thresh(drop_p) : 0u; p.drop_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f; p.seed = seed;
     dim3 grid((L + AT_Q - 1) / AT_Q, B * heads);
     ProfScope prof(PROF_ATTN, 4.0 * (double)B * heads * L * S * d, (hipStream_t)stream);
+    if (attn_mfma_applicable(L, S, d, dtype, ldq, ldk, ldv, ldo) && aligned16(q) && aligned16(k) && aligned16(v) && aligned8(o))
+        return attn_mfma_fwd(to_mfma(p), (hipStream_t)stream);
     if (dtype == PSG_F32) hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, p);
     PSG_LAUNCH_CHECK("attn_fwd");
@@ -378,6 +407,12 @@ int psg_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const v
     const int gdelta = (int)((rows + 3) / 4);
     dim3 gq((L + AT_Q - 1) / AT_Q, B * heads), gkv((S + AT_Q - 1) / AT_Q, B * heads);
     ProfScope prof(PROF_ATTN, 10.0 * (double)B * heads * L * S * d, s);
+    if (attn_mfma_applicable(L, S, d, dtype, ldq, ldk, ldv, ldo) && ((lddo | lddq | lddk | lddv) & 7) == 0 && aligned16(q) && aligned16(k) &&
+        aligned16(v) && aligned16(dout) && aligned8(dq) && aligned8(dk) && aligned8(dv)) {
+        hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, dim3(gdelta), dim3(256), 0, s, p);
+        PSG_LAUNCH_CHECK("attn_delta");
+        return attn_mfma_bwd(to_mfma(p), s);
+    }
     if (dtype == PSG_F32) {
         hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(gdelta), dim3(256), 0, s, p);
         hipLaunchKernelGGL(attn_dq_kernel<float>, gq, dim3(256), l1, s, p);

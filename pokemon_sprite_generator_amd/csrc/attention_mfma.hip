@@ -1,0 +1,435 @@
+// bf16 multi-head attention core on the matrix cores (v_mfma_f32_32x32x16_bf16), fused
+// QK^T -> softmax -> PV per (sample, head), plus the two backward kernels (dQ; dK+dV).
+//
+// One 256-thread workgroup (4 waves) per (b, head).  K and V of the head ([S][d], S <= 224 here)
+// are staged ONCE into LDS in their natural row-major layout (row stride 2*d32+16 bytes: an odd
+// number of 16-byte slots, so ds_read_b128 row fragments are conflict-free).  Each wave owns
+// 32-query tiles:
+//   S^T[key][q] = K . Q^T      MFMA A = K rows (ds_read_b128), B = Q^T (registers, straight from HBM)
+// so every lane holds ONE query column: the row softmax is an in-lane reduction over the 16
+// accumulator registers plus one cross-half __shfl_xor(32) — no LDS, no serial lanes.  The
+// exponentiated tile is converted to bf16 in registers and fed back as the B operand of
+//   O^T[d][q] += V^T . P^T     MFMA A = V^T fragments via ds_read_b64_tr_b16 (hardware transpose)
+// using the accumulator-as-operand k-order of the CDNA4 guide (element j of lane-half h is key
+// 16s + 8(j>>2) + 4h + (j&3)); the transposed reads pick the same key order.  Online softmax
+// (running max / sum per lane) over key tiles of 32.  Backward recomputes P from the saved
+// log-sum-exp: the dQ kernel has the same query-on-lane structure (dS^T is directly the B
+// operand of dQ^T += K^T . dS^T); the dK/dV kernel puts the KEY on the lane so that P and dS
+// are directly the B operands of dV^T += dO^T . P and dK^T += Q^T . dS.
+// Dropout uses the same stateless hash as the fp32 path (attn_idx), so masks agree in fwd/bwd.
+#include "psg_common.h"
+
+namespace psg {
+
+struct AttnMP {     // mirrored in attention.hip
+    const bf16_t *q, *k, *v, *o, *dout;
+    bf16_t *out, *dq, *dk, *dv;
+    float* lse; const float* delta;
+    int64_t ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+    int B, H, L, S, d;
+    float scale;
+    uint32_t drop_thresh; float drop_scale; uint64_t seed;
+};
+
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+#define LDS_TR(ptr) __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ptr))
+
+__device__ __forceinline__ bf16x8 cat_tr(s16x4 a, s16x4 b) {
+    s16x8 v = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    return *reinterpret_cast<bf16x8*>(&v);
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x16& x, int s2) {   // registers 8*s2 .. 8*s2+7 -> bf16x8
+    bf16x8 r;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = (bf16_t)x[8 * s2 + j];
+    return r;
+}
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// stage rows [0, nrows) of a [*, d] bf16 matrix into LDS rows of `stride` bytes, zero-filling rows >= nvalid
+// and columns [d, d32)
+__device__ __forceinline__ void stage_tile(char* dst, const bf16_t* src, int64_t ld, int row0, int nrows, int nvalid_end,
+                                           int d, int d32, int stride, int tid, int nthreads) {
+    const int cpr = d32 >> 3;                      // 16-byte chunks per row
+    for (int e = tid; e < nrows * cpr; e += nthreads) {
+        const int r = e / cpr, c = e - r * cpr;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        const int gr = row0 + r;
+        if (gr < nvalid_end && c * 8 < d) v = *reinterpret_cast<const uint4*>(src + (int64_t)gr * ld + c * 8);
+        *reinterpret_cast<uint4*>(dst + r * stride + c * 16) = v;
+    }
+}
+
+// transposed A-operand fragment for k-step s2 of a 32-row tile starting at row `row0` of an LDS image
+// [rows][stride]: output tile rows = columns colbase .. colbase+31 of the image; element j <-> image row
+// row0 + 16*s2 + 8*(j>>2) + 4*h + (j&3)
+__device__ __forceinline__ bf16x8 tr_frag(const char* img, int stride, int row0, int s2, int colbase, int lane) {
+    const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
+    const int h = g >> 1;
+    const char* base = img + (row0 + 16 * s2 + 4 * h + q4) * stride + (colbase + (g & 1) * 16 + 4 * p4) * 2;
+    s16x4 a = LDS_TR(base);
+    s16x4 b = LDS_TR(base + 8 * stride);
+    return cat_tr(a, b);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------
+template <int ND>
+__global__ __launch_bounds__(256) void attn_fwd_mfma(const AttnMP p) {
+    constexpr int NDT = (ND + 1) / 2;
+    constexpr int D32 = NDT * 32;
+    constexpr int STR = 2 * D32 + 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int Sp = (p.S + 31) & ~31;
+    char* Ks = smem;
+    char* Vs = smem + Sp * STR;
+    const int bh = blockIdx.x, b = bh / p.H, hd = bh - b * p.H;
+    const int d = ND * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bf16_t* qg = p.q + (int64_t)b * p.L * p.ldq + hd * d;
+    const bf16_t* kg = p.k + (int64_t)b * p.S * p.ldk + hd * d;
+    const bf16_t* vg = p.v + (int64_t)b * p.S * p.ldv + hd * d;
+    bf16_t* og = p.out + (int64_t)b * p.L * p.ldo + hd * d;
+    stage_tile(Ks, kg, p.ldk, 0, Sp, p.S, d, D32, STR, tid, 256);
+    stage_tile(Vs, vg, p.ldv, 0, Sp, p.S, d, D32, STR, tid, 256);
+    __syncthreads();
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const int nkt = Sp >> 5;
+    for (int qt = wave; qt * 32 < p.L; qt += 4) {
+        const int l = qt * 32 + fr;
+        const bool lok = l < p.L;
+        bf16x8 qf[ND];
+#pragma unroll
+        for (int ks = 0; ks < ND; ++ks) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (lok) v = *reinterpret_cast<const uint4*>(qg + (int64_t)l * p.ldq + 16 * ks + 8 * fh);
+            qf[ks] = *reinterpret_cast<bf16x8*>(&v);
+        }
+        f32x16 oacc[NDT];
+#pragma unroll
+        for (int t = 0; t < NDT; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) oacc[t][e] = 0.f;
+        float m = -INFINITY, lsum = 0.f;
+        for (int kt = 0; kt < nkt; ++kt) {
+            f32x16 st;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) st[e] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < ND; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + fr) * STR + (16 * ks + 8 * fh) * 2);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st, 0, 0, 0);
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + acc_row(r, fh);
+                st[r] = key < p.S ? st[r] * p.scale : -INFINITY;
+                mx = fmaxf(mx, st[r]);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mn = fmaxf(m, mx);
+            const float alpha = __expf(m - mn);
+            float ps = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { st[r] = __expf(st[r] - mn); ps += st[r]; }
+            lsum = lsum * alpha + ps;
+            m = mn;
+            if (p.drop_thresh) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * 32 + acc_row(r, fh);
+                    st[r] = (lok && key < p.S && drop_keep(p.seed, ((uint64_t)bh * p.L + l) * p.S + key, p.drop_thresh)) ? st[r] * p.drop_scale : 0.f;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NDT; ++t)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) oacc[t][e] *= alpha;
+            const bf16x8 pf0 = pack8(st, 0), pf1 = pack8(st, 1);
+#pragma unroll
+            for (int t = 0; t < NDT; ++t) {
+                const bf16x8 v0 = tr_frag(Vs, STR, kt * 32, 0, t * 32, lane);
+                const bf16x8 v1 = tr_frag(Vs, STR, kt * 32, 1, t * 32, lane);
+                oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pf0, oacc[t], 0, 0, 0);
+                oacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pf1, oacc[t], 0, 0, 0);
+            }
+        }
+        const float ltot = lsum + __shfl_xor(lsum, 32, 64);
+        const float inv = 1.0f / ltot;
+        if (lok) {
+            if (fh == 0) p.lse[(int64_t)bh * p.L + l] = m + __logf(ltot);
+#pragma unroll
+            for (int t = 0; t < NDT; ++t)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int dd = t * 32 + 8 * g4 + 4 * fh;
+                    if (dd < d) {
+                        f32x4 v = {oacc[t][4 * g4] * inv, oacc[t][4 * g4 + 1] * inv, oacc[t][4 * g4 + 2] * inv, oacc[t][4 * g4 + 3] * inv};
+                        store4<bf16_t>(og + (int64_t)l * p.ldo + dd, v);
+                    }
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dQ: same query-on-lane structure
+// ------------------------------------------------------------------------------------------------
+template <int ND>
+__global__ __launch_bounds__(256) void attn_dq_mfma(const AttnMP p) {
+    constexpr int NDT = (ND + 1) / 2;
+    constexpr int D32 = NDT * 32;
+    constexpr int STR = 2 * D32 + 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int Sp = (p.S + 31) & ~31;
+    char* Ks = smem;
+    char* Vs = smem + Sp * STR;
+    const int bh = blockIdx.x, b = bh / p.H, hd = bh - b * p.H;
+    const int d = ND * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bf16_t* qg = p.q + (int64_t)b * p.L * p.ldq + hd * d;
+    const bf16_t* kg = p.k + (int64_t)b * p.S * p.ldk + hd * d;
+    const bf16_t* vg = p.v + (int64_t)b * p.S * p.ldv + hd * d;
+    const bf16_t* gg = p.dout + (int64_t)b * p.L * p.lddo + hd * d;
+    bf16_t* dqg = p.dq + (int64_t)b * p.L * p.lddq + hd * d;
+    stage_tile(Ks, kg, p.ldk, 0, Sp, p.S, d, D32, STR, tid, 256);
+    stage_tile(Vs, vg, p.ldv, 0, Sp, p.S, d, D32, STR, tid, 256);
+    __syncthreads();
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const int nkt = Sp >> 5;
+    for (int qt = wave; qt * 32 < p.L; qt += 4) {
+        const int l = qt * 32 + fr;
+        const bool lok = l < p.L;
+        bf16x8 qf[ND], gf[ND];
+#pragma unroll
+        for (int ks = 0; ks < ND; ++ks) {
+            uint4 v = make_uint4(0, 0, 0, 0), w = make_uint4(0, 0, 0, 0);
+            if (lok) {
+                v = *reinterpret_cast<const uint4*>(qg + (int64_t)l * p.ldq + 16 * ks + 8 * fh);
+                w = *reinterpret_cast<const uint4*>(gg + (int64_t)l * p.lddo + 16 * ks + 8 * fh);
+            }
+            qf[ks] = *reinterpret_cast<bf16x8*>(&v);
+            gf[ks] = *reinterpret_cast<bf16x8*>(&w);
+        }
+        const float lse = lok ? p.lse[(int64_t)bh * p.L + l] : 0.f;
+        const float del = lok ? p.delta[(int64_t)bh * p.L + l] : 0.f;
+        f32x16 dacc[NDT];
+#pragma unroll
+        for (int t = 0; t < NDT; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dacc[t][e] = 0.f;
+        for (int kt = 0; kt < nkt; ++kt) {
+            f32x16 st, dp;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { st[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < ND; ++ks) {
+                const bf16x8 kf = *reinterpret_cast<const bf16x8*>(Ks + (kt * 32 + fr) * STR + (16 * ks + 8 * fh) * 2);
+                const bf16x8 vf = *reinterpret_cast<const bf16x8*>(Vs + (kt * 32 + fr) * STR + (16 * ks + 8 * fh) * 2);
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st, 0, 0, 0);
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, gf[ks], dp, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kt * 32 + acc_row(r, fh);
+                float ds = 0.f;
+                if (lok && key < p.S) {
+                    const float pr = __expf(st[r] * p.scale - lse);
+                    float dpr = dp[r];
+                    if (p.drop_thresh) dpr = drop_keep(p.seed, ((uint64_t)bh * p.L + l) * p.S + key, p.drop_thresh) ? dpr * p.drop_scale : 0.f;
+                    ds = pr * (dpr - del) * p.scale;
+                }
+                st[r] = ds;
+            }
+            const bf16x8 sf0 = pack8(st, 0), sf1 = pack8(st, 1);
+#pragma unroll
+            for (int t = 0; t < NDT; ++t) {
+                const bf16x8 k0 = tr_frag(Ks, STR, kt * 32, 0, t * 32, lane);
+                const bf16x8 k1 = tr_frag(Ks, STR, kt * 32, 1, t * 32, lane);
+                dacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, sf0, dacc[t], 0, 0, 0);
+                dacc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, sf1, dacc[t], 0, 0, 0);
+            }
+        }
+        if (lok) {
+#pragma unroll
+            for (int t = 0; t < NDT; ++t)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int dd = t * 32 + 8 * g4 + 4 * fh;
+                    if (dd < d) {
+                        f32x4 v = {dacc[t][4 * g4], dacc[t][4 * g4 + 1], dacc[t][4 * g4 + 2], dacc[t][4 * g4 + 3]};
+                        store4<bf16_t>(dqg + (int64_t)l * p.lddq + dd, v);
+                    }
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dK, dV: key on the lane.  Q and dO of the whole head live in LDS; each wave stages its own 32-key
+// K/V tile (row reads for the B operands) into a private LDS region.
+// ------------------------------------------------------------------------------------------------
+template <int ND>
+__global__ __launch_bounds__(256) void attn_dkv_mfma(const AttnMP p) {
+    constexpr int NDT = (ND + 1) / 2;
+    constexpr int D32 = NDT * 32;
+    constexpr int STR = 2 * D32 + 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int Lp = (p.L + 31) & ~31;
+    char* Qs = smem;
+    char* Gs = Qs + Lp * STR;
+    float* Ls = reinterpret_cast<float*>(Gs + Lp * STR);     // lse[Lp], delta[Lp]
+    float* Dl = Ls + Lp;
+    char* KVw = reinterpret_cast<char*>(Dl + Lp);            // per wave: K tile [32][STR] | V tile [32][STR]
+    const int bh = blockIdx.x, b = bh / p.H, hd = bh - b * p.H;
+    const int d = ND * 16;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bf16_t* qg = p.q + (int64_t)b * p.L * p.ldq + hd * d;
+    const bf16_t* kg = p.k + (int64_t)b * p.S * p.ldk + hd * d;
+    const bf16_t* vg = p.v + (int64_t)b * p.S * p.ldv + hd * d;
+    const bf16_t* gg = p.dout + (int64_t)b * p.L * p.lddo + hd * d;
+    bf16_t* dkg = p.dk + (int64_t)b * p.S * p.lddk + hd * d;
+    bf16_t* dvg = p.dv + (int64_t)b * p.S * p.lddv + hd * d;
+    stage_tile(Qs, qg, p.ldq, 0, Lp, p.L, d, D32, STR, tid, 256);
+    stage_tile(Gs, gg, p.lddo, 0, Lp, p.L, d, D32, STR, tid, 256);
+    for (int i = tid; i < Lp; i += 256) {
+        Ls[i] = i < p.L ? p.lse[(int64_t)bh * p.L + i] : 0.f;
+        Dl[i] = i < p.L ? p.delta[(int64_t)bh * p.L + i] : 0.f;
+    }
+    __syncthreads();
+
+    const int fr = lane & 31, fh = lane >> 5;
+    const int Sp = (p.S + 31) & ~31;
+    const int nqt = Lp >> 5;
+    char* Kw = KVw + wave * (2 * 32 * STR);
+    char* Vw = Kw + 32 * STR;
+    for (int kt = wave; kt * 32 < Sp; kt += 4) {
+        // private K/V tile (only this wave touches Kw/Vw: wave-level ordering suffices)
+        stage_tile(Kw, kg, p.ldk, kt * 32, 32, p.S, d, D32, STR, lane, 64);
+        stage_tile(Vw, vg, p.ldv, kt * 32, 32, p.S, d, D32, STR, lane, 64);
+        __builtin_amdgcn_s_waitcnt(0);     // all counters: the wave's own LDS writes have landed
+        __builtin_amdgcn_wave_barrier();
+        const int key = kt * 32 + fr;
+        const bool kok = key < p.S;
+        f32x16 dk[NDT], dv[NDT];
+#pragma unroll
+        for (int t = 0; t < NDT; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { dk[t][e] = 0.f; dv[t][e] = 0.f; }
+        for (int qt = 0; qt < nqt; ++qt) {
+            f32x16 st, dp;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { st[e] = 0.f; dp[e] = 0.f; }
+#pragma unroll
+            for (int ks = 0; ks < ND; ++ks) {
+                const int co = (16 * ks + 8 * fh) * 2;
+                const bf16x8 qa = *reinterpret_cast<const bf16x8*>(Qs + (qt * 32 + fr) * STR + co);     // A: Q rows
+                const bf16x8 ga = *reinterpret_cast<const bf16x8*>(Gs + (qt * 32 + fr) * STR + co);     // A: dO rows
+                const bf16x8 kb = *reinterpret_cast<const bf16x8*>(Kw + fr * STR + co);                  // B: K^T (key on lane)
+                const bf16x8 vb = *reinterpret_cast<const bf16x8*>(Vw + fr * STR + co);                  // B: V^T
+                st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kb, st, 0, 0, 0);    // S[q][key]
+                dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, vb, dp, 0, 0, 0);    // dP[q][key]
+            }
+            f32x16 pd;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int l = qt * 32 + acc_row(r, fh);
+                float pv = 0.f, ds = 0.f;
+                if (kok && l < p.L) {
+                    const float pr = __expf(st[r] * p.scale - Ls[l]);
+                    float dpr = dp[r];
+                    pv = pr;
+                    if (p.drop_thresh) {
+                        const bool keep = drop_keep(p.seed, ((uint64_t)bh * p.L + l) * p.S + key, p.drop_thresh);
+                        pv = keep ? pr * p.drop_scale : 0.f;
+                        dpr = keep ? dpr * p.drop_scale : 0.f;
+                    }
+                    ds = pr * (dpr - Dl[l]) * p.scale;
+                }
+                pd[r] = pv; st[r] = ds;
+            }
+            const bf16x8 pf0 = pack8(pd, 0), pf1 = pack8(pd, 1), sf0 = pack8(st, 0), sf1 = pack8(st, 1);
+#pragma unroll
+            for (int t = 0; t < NDT; ++t) {
+                const bf16x8 g0 = tr_frag(Gs, STR, qt * 32, 0, t * 32, lane);
+                const bf16x8 g1 = tr_frag(Gs, STR, qt * 32, 1, t * 32, lane);
+                dv[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, pf0, dv[t], 0, 0, 0);   // dV^T[d][key] += dO^T . P
+                dv[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, pf1, dv[t], 0, 0, 0);
+                const bf16x8 q0 = tr_frag(Qs, STR, qt * 32, 0, t * 32, lane);
+                const bf16x8 q1 = tr_frag(Qs, STR, qt * 32, 1, t * 32, lane);
+                dk[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0, sf0, dk[t], 0, 0, 0);   // dK^T[d][key] += Q^T . dS
+                dk[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1, sf1, dk[t], 0, 0, 0);
+            }
+        }
+        if (kok) {
+#pragma unroll
+            for (int t = 0; t < NDT; ++t)
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int dd = t * 32 + 8 * g4 + 4 * fh;
+                    if (dd < d) {
+                        f32x4 a = {dk[t][4 * g4], dk[t][4 * g4 + 1], dk[t][4 * g4 + 2], dk[t][4 * g4 + 3]};
+                        f32x4 c = {dv[t][4 * g4], dv[t][4 * g4 + 1], dv[t][4 * g4 + 2], dv[t][4 * g4 + 3]};
+                        store4<bf16_t>(dkg + (int64_t)key * p.lddk + dd, a);
+                        store4<bf16_t>(dvg + (int64_t)key * p.lddv + dd, c);
+                    }
+                }
+        }
+        __builtin_amdgcn_wave_barrier();    // tile reads done before the next restage (same wave, program order)
+    }
+}
+
+static inline int nd_supported(int d) { return d == 16 || d == 32 || d == 80 || d == 160; }
+static inline size_t str_bytes(int d) { return 2 * (size_t)(((d + 31) / 32) * 32) + 16; }
+static inline size_t fwd_lds_m(int S, int d) { return 2 * (size_t)((S + 31) & ~31) * str_bytes(d); }
+static inline size_t dkv_lds_m(int L, int d) {
+    const size_t Lp = (L + 31) & ~31;
+    return 2 * Lp * str_bytes(d) + 2 * Lp * sizeof(float) + 4 * 2 * 32 * str_bytes(d);
+}
+constexpr size_t MFMA_LDS_CAP = 158 * 1024;
+
+// returns 1 when the MFMA path handles this problem
+int attn_mfma_applicable(int L, int S, int d, int dtype, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo) {
+    if (dtype != PSG_BF16 || !nd_supported(d)) return 0;
+    if (((ldq | ldk | ldv | ldo) & 7) != 0) return 0;                    // 16-byte row fragments
+    if (fwd_lds_m(S, d) > MFMA_LDS_CAP || dkv_lds_m(L, d) > MFMA_LDS_CAP) return 0;
+    return 1;
+}
+
+#define ND_DISPATCH(KERNEL, ...)                                                                      \
+    switch (d) {                                                                                      \
+        case 16: hipLaunchKernelGGL(KERNEL<1>, __VA_ARGS__); break;                                   \
+        case 32: hipLaunchKernelGGL(KERNEL<2>, __VA_ARGS__); break;                                   \
+        case 80: hipLaunchKernelGGL(KERNEL<5>, __VA_ARGS__); break;                                   \
+        default: hipLaunchKernelGGL(KERNEL<10>, __VA_ARGS__); break;                                  \
+    }
+
+int attn_mfma_init_attrs() {
+#define SET_LDS(K) PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MFMA_LDS_CAP))
+    SET_LDS(attn_fwd_mfma<1>); SET_LDS(attn_fwd_mfma<2>); SET_LDS(attn_fwd_mfma<5>); SET_LDS(attn_fwd_mfma<10>);
+    SET_LDS(attn_dq_mfma<1>); SET_LDS(attn_dq_mfma<2>); SET_LDS(attn_dq_mfma<5>); SET_LDS(attn_dq_mfma<10>);
+    SET_LDS(attn_dkv_mfma<1>); SET_LDS(attn_dkv_mfma<2>); SET_LDS(attn_dkv_mfma<5>); SET_LDS(attn_dkv_mfma<10>);
+#undef SET_LDS
+    return PSG_OK;
+}
+
+int attn_mfma_fwd(const AttnMP& p, hipStream_t s) {
+    const int d = p.d;
+    ND_DISPATCH(attn_fwd_mfma, dim3(p.B * p.H), dim3(256), fwd_lds_m(p.S, d), s, p);
+    PSG_LAUNCH_CHECK("attn_fwd_mfma");
+    return PSG_OK;
+}
+int attn_mfma_bwd(const AttnMP& p, hipStream_t s) {
+    const int d = p.d;
+    ND_DISPATCH(attn_dq_mfma, dim3(p.B * p.H), dim3(256), fwd_lds_m(p.S, d), s, p);
+    PSG_LAUNCH_CHECK("attn_dq_mfma");
+    ND_DISPATCH(attn_dkv_mfma, dim3(p.B * p.H), dim3(256), dkv_lds_m(p.L, d), s, p);
+    PSG_LAUNCH_CHECK("attn_dkv_mfma");
+    return PSG_OK;
+}
+
+}  // namespace psg

@@ -378,34 +378,38 @@ __global__ void prep_weight_kernel(const float* __restrict__ w, T* __restrict__ 
 // column sums (bias gradient / per-sample rowadd gradient), deterministic 2-stage
 // grid: (col blocks of 64*4 columns... see launcher)
 // ---------------------------------------------------------------------------
-template <typename T>
-__global__ void colsum_stage1(const T* __restrict__ a, int64_t lda, float* __restrict__ partial,
-                              int64_t R, int groups, int cols, int splits, int64_t rows_per_split) {
-    // blockIdx.x: column block (blockDim.x columns... each thread 1 column), blockIdx.y: group*splits + split
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// out[(g*splits + s), c] = sum of rows [s*rps, (s+1)*rps) of group g.  256 threads = 64 columns x 4 row lanes,
+// 4 independent loads in flight per lane, LDS combine: coalesced 128/256-byte row segments, fixed order.
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void colsum_tile(const TI* __restrict__ a, int64_t lda, TO* __restrict__ out, int64_t ld_out,
+                                                   int64_t R, int cols, int splits, int64_t rps, int accumulate) {
+    __shared__ float red[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     const int gs = blockIdx.y;
-    const int g = gs / splits, s = gs % splits;
-    if (c >= cols) return;
-    const int64_t r0 = (int64_t)s * rows_per_split;
-    int64_t r1 = r0 + rows_per_split;
+    const int g = gs / splits, s = gs - g * splits;
+    const int64_t r0 = (int64_t)s * rps;
+    int64_t r1 = r0 + rps;
     if (r1 > R) r1 = R;
-    float acc = 0.f;
-    const T* base = a + ((int64_t)g * R) * lda + c;
-    for (int64_t r = r0; r < r1; ++r) acc += Elem<T>::ld(base + r * lda);
-    partial[(int64_t)gs * cols + c] = acc;
-}
-template <typename TO>
-__global__ void colsum_stage2(const float* __restrict__ partial, TO* __restrict__ out, int64_t ld_out,
-                              int groups, int cols, int splits, int accumulate) {
-    const int64_t n = (int64_t)groups * cols;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % cols);
-        const int64_t g = i / cols;
-        float acc = 0.f;
-        for (int s = 0; s < splits; ++s) acc += partial[((int64_t)g * splits + s) * cols + c];
-        TO* o = out + g * ld_out + c;
-        if (accumulate) acc += Elem<TO>::ld(o);
-        Elem<TO>::st(o, acc);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    if (c < cols) {
+        const TI* base = a + ((int64_t)g * R) * lda + c;
+        int64_t r = r0 + rl;
+        for (; r + 12 < r1; r += 16) {
+            a0 += Elem<TI>::ld(base + r * lda);
+            a1 += Elem<TI>::ld(base + (r + 4) * lda);
+            a2 += Elem<TI>::ld(base + (r + 8) * lda);
+            a3 += Elem<TI>::ld(base + (r + 12) * lda);
+        }
+        for (; r < r1; r += 4) a0 += Elem<TI>::ld(base + r * lda);
+    }
+    red[rl][cl] = (a0 + a1) + (a2 + a3);
+    __syncthreads();
+    if (rl == 0 && c < cols) {
+        float v = (red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl]);
+        TO* o = out + (int64_t)gs * ld_out + c;
+        if (accumulate) v += Elem<TO>::ld(o);
+        Elem<TO>::st(o, v);
     }
 }
 
@@ -656,11 +660,12 @@ int psg_prep_weight(const float* w, void* wf, void* wd, int O, int I, int ksize,
     return PSG_OK;
 }
 
-static inline void colsum_plan(int64_t R, int groups, int& splits, int64_t& rps) {
-    // aim for >= 512 row-splits*groups in flight, at least 32 rows per split
-    int64_t want = (512 + groups - 1) / groups;
-    int64_t maxs = (R + 31) / 32;
+static inline void colsum_plan(int64_t R, int groups, int cols, int& splits, int64_t& rps) {
+    const int64_t cb = (cols + 63) / 64;
+    int64_t want = 2048 / (cb * groups);          // ~8 workgroups per CU in flight
+    const int64_t maxs = (R + 63) / 64;           // at least 64 rows per split
     if (want > maxs) want = maxs;
+    if (want > 256) want = 256;
     if (want < 1) want = 1;
     rps = (R + want - 1) / want;
     splits = (int)((R + rps - 1) / rps);
@@ -668,7 +673,7 @@ static inline void colsum_plan(int64_t R, int groups, int& splits, int64_t& rps)
 
 int64_t psg_colsum_workspace_bytes(int64_t R, int groups, int cols) {
     int splits; int64_t rps;
-    colsum_plan(R, groups, splits, rps);
+    colsum_plan(R, groups, cols, splits, rps);
     return (int64_t)groups * splits * cols * sizeof(float);
 }
 
@@ -678,17 +683,29 @@ int psg_colsum(const void* a, int64_t lda, void* out, int64_t ld_out, int64_t R,
     PSG_REQUIRE(R > 0 && groups > 0 && cols > 0 && lda >= cols && ld_out >= cols, PSG_ERR_SHAPE, "colsum: bad shape");
     PSG_REQUIRE(ws_bytes >= psg_colsum_workspace_bytes(R, groups, cols), PSG_ERR_WORKSPACE, "colsum: workspace too small");
     PSG_REQUIRE(!(accumulate && out_dtype != PSG_F32), PSG_ERR_ARG, "colsum: accumulate needs fp32 out");
+    PSG_REQUIRE(dtype == PSG_F32 || dtype == PSG_BF16, PSG_ERR_DTYPE, "colsum: dtype %d", dtype);
+    PSG_REQUIRE(out_dtype == PSG_F32 || out_dtype == PSG_BF16, PSG_ERR_DTYPE, "colsum: out_dtype %d", out_dtype);
     int splits; int64_t rps;
-    colsum_plan(R, groups, splits, rps);
-    dim3 g1((cols + 63) / 64, groups * splits);
-    DISPATCH_DTYPE(dtype,
-        hipLaunchKernelGGL(colsum_stage1<float>, g1, dim3(64), 0, (hipStream_t)stream, (const float*)a, lda, (float*)ws, R, groups, cols, splits, rps),
-        hipLaunchKernelGGL(colsum_stage1<bf16_t>, g1, dim3(64), 0, (hipStream_t)stream, (const bf16_t*)a, lda, (float*)ws, R, groups, cols, splits, rps));
+    colsum_plan(R, groups, cols, splits, rps);
+    hipStream_t st = (hipStream_t)stream;
+    const int cb = (cols + 63) / 64;
+    float* wsf = (float*)ws;
+    if (splits == 1) {      // single pass straight into the output
+        dim3 g1(cb, groups);
+        if (dtype == PSG_F32 && out_dtype == PSG_F32) hipLaunchKernelGGL((colsum_tile<float, float>), g1, dim3(256), 0, st, (const float*)a, lda, (float*)out, ld_out, R, cols, 1, R, accumulate);
+        else if (dtype == PSG_F32) hipLaunchKernelGGL((colsum_tile<float, bf16_t>), g1, dim3(256), 0, st, (const float*)a, lda, (bf16_t*)out, ld_out, R, cols, 1, R, 0);
+        else if (out_dtype == PSG_F32) hipLaunchKernelGGL((colsum_tile<bf16_t, float>), g1, dim3(256), 0, st, (const bf16_t*)a, lda, (float*)out, ld_out, R, cols, 1, R, accumulate);
+        else hipLaunchKernelGGL((colsum_tile<bf16_t, bf16_t>), g1, dim3(256), 0, st, (const bf16_t*)a, lda, (bf16_t*)out, ld_out, R, cols, 1, R, 0);
+        PSG_LAUNCH_CHECK("colsum");
+        return PSG_OK;
+    }
+    dim3 g1(cb, groups * splits);
+    if (dtype == PSG_F32) hipLaunchKernelGGL((colsum_tile<float, float>), g1, dim3(256), 0, st, (const float*)a, lda, wsf, (int64_t)cols, R, cols, splits, rps, 0);
+    else hipLaunchKernelGGL((colsum_tile<bf16_t, float>), g1, dim3(256), 0, st, (const bf16_t*)a, lda, wsf, (int64_t)cols, R, cols, splits, rps, 0);
     PSG_LAUNCH_CHECK("colsum_stage1");
-    const int g2 = grid_for((int64_t)groups * cols, 256);
-    DISPATCH_DTYPE(out_dtype,
-        hipLaunchKernelGGL(colsum_stage2<float>, dim3(g2), dim3(256), 0, (hipStream_t)stream, (const float*)ws, (float*)out, ld_out, groups, cols, splits, accumulate),
-        hipLaunchKernelGGL(colsum_stage2<bf16_t>, dim3(g2), dim3(256), 0, (hipStream_t)stream, (const float*)ws, (bf16_t*)out, ld_out, groups, cols, splits, accumulate));
+    dim3 g2(cb, groups);    // second stage: the partial slab [groups][splits][cols] is itself a column-sum problem
+    if (out_dtype == PSG_F32) hipLaunchKernelGGL((colsum_tile<float, float>), g2, dim3(256), 0, st, (const float*)wsf, (int64_t)cols, (float*)out, ld_out, (int64_t)splits, cols, 1, (int64_t)splits, accumulate);
+    else hipLaunchKernelGGL((colsum_tile<float, bf16_t>), g2, dim3(256), 0, st, (const float*)wsf, (int64_t)cols, (bf16_t*)out, ld_out, (int64_t)splits, cols, 1, (int64_t)splits, 0);
     PSG_LAUNCH_CHECK("colsum_stage2");
     return PSG_OK;
 }

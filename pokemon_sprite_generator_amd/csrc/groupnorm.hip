@@ -176,15 +176,24 @@ __global__ __launch_bounds__(GN_THREADS) void gn_bwd_kernel(
 // NOTE (aliasing): when dx aliases dy and the slab is NOT in LDS, pass C would read dy after pass B
 // overwrote it; the launcher forbids aliasing in that case.
 
-__global__ void gn_param_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dgamma,
-                                       float* __restrict__ dbeta, int B, int C, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// dgamma/dbeta[c] (+)= sum_b ws[{0,1}][b][c]: 64 columns x 4 batch lanes per block, fixed order
+__global__ __launch_bounds__(256) void gn_param_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, int B, int C, int accumulate) {
+    __shared__ float red[2][4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     float ag = 0.f, ab = 0.f;
-    for (int b = 0; b < B; ++b) { ag += ws[(int64_t)b * C + c]; ab += ws[(int64_t)B * C + (int64_t)b * C + c]; }
-    if (accumulate) { ag += dgamma[c]; ab += dbeta[c]; }
-    dgamma[c] = ag;
-    dbeta[c] = ab;
+    if (c < C)
+        for (int b = rl; b < B; b += 4) { ag += ws[(int64_t)b * C + c]; ab += ws[(int64_t)B * C + (int64_t)b * C + c]; }
+    red[0][rl][cl] = ag; red[1][rl][cl] = ab;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        ag = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+        ab = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+        if (accumulate) { ag += dgamma[c]; ab += dbeta[c]; }
+        dgamma[c] = ag;
+        dbeta[c] = ab;
+    }
 }
 
 }  // namespace psg
@@ -254,7 +263,7 @@ int psg_groupnorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, 
                            (const bf16_t*)x, ldx, gamma, beta, mean, rstd, (bf16_t*)dx, lddx, (float*)ws, B, HW, C, G, silu);
     else return set_error(PSG_ERR_DTYPE, "groupnorm_bwd: dtype %d", dtype);
     PSG_LAUNCH_CHECK("groupnorm_bwd");
-    hipLaunchKernelGGL(gn_param_reduce_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)ws, dgamma,
+    hipLaunchKernelGGL(gn_param_reduce_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const float*)ws, dgamma,
                        dbeta, B, C, accumulate);
     PSG_LAUNCH_CHECK("groupnorm_param_reduce");
     return PSG_OK;
