@@ -31,6 +31,7 @@ struct ConvP {
     int mtiles, ntiles;
     int act; float alpha;
     uint32_t drop_thresh; float drop_scale; uint64_t drop_seed;
+    uint32_t x_bytes, w_bytes;     // extents for the bounds-checked buffer loads
 };
 
 template <typename T> struct Mma;
@@ -54,7 +55,10 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {   // byte offset in
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
-template <typename T, int BM, int BN>
+// MODE 0: forward gather, K step inside one tap (Cin % K-step == 0)   [every 3x3 / 1x1 layer of the U-Net body]
+// MODE 1: data-gradient gather of a stride-1 conv, same fast decode
+// MODE 2: generic (stride-2 data gradient, Cin = 8 first/last convs): per-thread tap decode
+template <typename T, int BM, int BN, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
     constexpr int CH = Elem<T>::CH;
     constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA tiles per wave along m / n
@@ -84,16 +88,20 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
     // ---- per-thread staging coordinates ------------------------------------
     const int sc = tid & 7;          // chunk column within the K step
     const int sr = tid >> 3;         // row within a 32-row pass
-    const T* xg = reinterpret_cast<const T*>(p.x);
-    const T* wg = reinterpret_cast<const T*>(p.w);
 
-    int64_t w_off[JW];               // element offset of the row start, or -1
+    // Branch-free gathers: raw buffer loads return 0 for an out-of-range offset, so padding taps,
+    // rows beyond M / N and the K tail cost no control flow (and no per-load s_waitcnt).
+    constexpr uint32_t OOB = 0x80000000u;          // extents are < 2 GiB (checked on the host)
+    constexpr int ESZ = (int)sizeof(T);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+    uint32_t w_off[JW];              // byte offset of (row, chunk sc), or OOB
 #pragma unroll
     for (int j = 0; j < JW; ++j) {
         const int n = n0 + sr + 32 * j;
-        w_off[j] = n < p.N ? (int64_t)n * p.ldw : -1;
+        w_off[j] = n < p.N ? (uint32_t)(((int64_t)n * p.ldw + sc * CH) * ESZ) : OOB;
     }
-    int x_hb[JX], x_wb[JX], x_pb[JX];
+    int x_hb[JX], x_wb[JX], x_base[JX];   // tap-0 source row / col, and byte offset of that pixel (+ chunk sc)
     {
         const int HoWo = p.Ho * p.Wo;
 #pragma unroll
@@ -104,47 +112,66 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
                 const int ho = rm / p.Wo, wo = rm - ho * p.Wo;
                 if (p.transposed) { x_hb[j] = ho + p.pad; x_wb[j] = wo + p.pad; }
                 else { x_hb[j] = ho * p.stride - p.pad; x_wb[j] = wo * p.stride - p.pad; }
-                x_pb[j] = b * p.Hi * p.Wi;
-            } else { x_hb[j] = -100000; x_wb[j] = -100000; x_pb[j] = 0; }
+                if (MODE == 2) x_base[j] = b * p.Hi * p.Wi;                       // pixel base only
+                else x_base[j] = ((b * p.Hi + x_hb[j]) * p.Wi + x_wb[j]) * (int)p.ldx * ESZ + sc * 16;
+            } else { x_hb[j] = -100000; x_wb[j] = -100000; x_base[j] = 0; }
         }
     }
 
-    uint4 gw[JW], gx[JX];
+    // uniform tap state of the NEXT K step to load (fast modes): chunk offset inside the tap, kh, kw
+    int t_c0 = 0, t_kh = 0, t_kw = 0;
+    u32x4 gw[JW], gx[JX];
     auto load_tiles = [&](int kt) {
-        // weights: always in-bounds along K (Kpad), rows masked by N
+        const uint32_t kbytes = (uint32_t)kt * 128u;          // 8 chunks of 16 B per K step
 #pragma unroll
-        for (int j = 0; j < JW; ++j) {
-            if (w_off[j] >= 0) gw[j] = *reinterpret_cast<const uint4*>(wg + w_off[j] + (int64_t)(kt * 8 + sc) * CH);
-            else gw[j] = make_uint4(0, 0, 0, 0);
-        }
-        // activations: tap / channel decode (uniform on the fast path)
-        int tap, cc;
-        if (p.fast) { tap = kt / p.tpt; cc = (kt - tap * p.tpt) * 8 + sc; }
-        else { const int qi = kt * 8 + sc; tap = qi / p.cpt; cc = qi - tap * p.cpt; }
-        const bool tap_ok = tap < p.taps;
-        const int kh = tap / p.ks, kw = tap - kh * p.ks;
+        for (int j = 0; j < JW; ++j) gw[j] = __builtin_amdgcn_raw_buffer_load_b128(wrs, w_off[j] + kbytes, 0, 0);
+        if (MODE != 2) {
+            const int sgn = MODE == 0 ? 1 : -1;
+            const int delta = (sgn * (t_kh * p.Wi + t_kw) * (int)p.ldx + t_c0 * CH) * ESZ;      // wave-uniform
 #pragma unroll
-        for (int j = 0; j < JX; ++j) {
-            int sh, sw; bool ok = tap_ok;
-            if (p.transposed) {
-                const int th = x_hb[j] - kh, tw = x_wb[j] - kw;
-                if (p.stride == 1) { sh = th; sw = tw; }
-                else { sh = th >> 1; sw = tw >> 1; ok = ok && ((th | tw) & 1) == 0; }
-                ok = ok && th >= 0 && tw >= 0 && sh < p.Hi && sw < p.Wi;
-            } else {
-                sh = x_hb[j] + kh; sw = x_wb[j] + kw;
-                ok = ok && sh >= 0 && sw >= 0 && sh < p.Hi && sw < p.Wi;
+            for (int j = 0; j < JX; ++j) {
+                const int sh = x_hb[j] + sgn * t_kh, sw = x_wb[j] + sgn * t_kw;
+                const bool ok = (unsigned)sh < (unsigned)p.Hi && (unsigned)sw < (unsigned)p.Wi;
+                uint32_t off = (uint32_t)(x_base[j] + delta);
+                off = ok ? off : OOB;
+                gx[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0);
             }
-            if (ok) gx[j] = *reinterpret_cast<const uint4*>(xg + (int64_t)(x_pb[j] + sh * p.Wi + sw) * p.ldx + cc * CH);
-            else gx[j] = make_uint4(0, 0, 0, 0);
+            t_c0 += 8;
+            if (t_c0 >= p.cpt) { t_c0 = 0; if (++t_kw == p.ks) { t_kw = 0; ++t_kh; } }
+        } else {
+            const int qi = kt * 8 + sc;
+            const int tap = qi / p.cpt, cc = qi - tap * p.cpt;
+            const bool tap_ok = tap < p.taps;
+            const int kh = tap / p.ks, kw = tap - kh * p.ks;
+#pragma unroll
+            for (int j = 0; j < JX; ++j) {
+                int sh, sw; bool ok = tap_ok;
+                if (p.transposed) {
+                    const int th = x_hb[j] - kh, tw = x_wb[j] - kw;
+                    if (p.stride == 1) { sh = th; sw = tw; }
+                    else { sh = th >> 1; sw = tw >> 1; ok = ok && ((th | tw) & 1) == 0; }
+                    ok = ok && th >= 0 && tw >= 0 && sh < p.Hi && sw < p.Wi;
+                } else {
+                    sh = x_hb[j] + kh; sw = x_wb[j] + kw;
+                    ok = ok && sh >= 0 && sw >= 0 && sh < p.Hi && sw < p.Wi;
+                }
+                uint32_t off = (uint32_t)(((x_base[j] + sh * p.Wi + sw) * (int)p.ldx + cc * CH) * ESZ);
+                off = ok ? off : OOB;
+                gx[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0);
+            }
         }
     };
+    int st_w[JW], st_x[JX];          // LDS byte offsets of this thread's staging slots (loop-invariant)
+#pragma unroll
+    for (int j = 0; j < JW; ++j) st_w[j] = lds_off(sr + 32 * j, sc);
+#pragma unroll
+    for (int j = 0; j < JX; ++j) st_x[j] = BN * 128 + lds_off(sr + 32 * j, sc);
     auto store_tiles = [&](int buf) {
         char* base = smem + buf * BUF_BYTES;
 #pragma unroll
-        for (int j = 0; j < JW; ++j) *reinterpret_cast<uint4*>(base + lds_off(sr + 32 * j, sc)) = gw[j];
+        for (int j = 0; j < JW; ++j) *reinterpret_cast<u32x4*>(base + st_w[j]) = gw[j];
 #pragma unroll
-        for (int j = 0; j < JX; ++j) *reinterpret_cast<uint4*>(base + BN * 128 + lds_off(sr + 32 * j, sc)) = gx[j];
+        for (int j = 0; j < JX; ++j) *reinterpret_cast<u32x4*>(base + st_x[j]) = gx[j];
     };
 
     f32x16 acc[TN][TM];
@@ -156,6 +183,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     const int fr = lane & 31, fh = lane >> 5;
+    int rd_w[TN], rd_x[TM];          // fragment row bases (bytes), chunk swizzle key
+    int sw_w[TN], sw_x[TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) { const int row = wn * (TN * 32) + i * 32 + fr; rd_w[i] = row * 128; sw_w[i] = (row >> 1) & 7; }
+#pragma unroll
+    for (int j = 0; j < TM; ++j) { const int row = wm * (TM * 32) + j * 32 + fr; rd_x[j] = BN * 128 + row * 128; sw_x[j] = (row >> 1) & 7; }
 
     load_tiles(0);
     store_tiles(0);
@@ -164,16 +197,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
     for (int kt = 0; kt < p.KT; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < p.KT) load_tiles(kt + 1);          // in flight during the MFMA phase
-        const char* wb = smem + buf * BUF_BYTES;
-        const char* xb = wb + BN * 128;
+        const char* tb = smem + buf * BUF_BYTES;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             const int c = 2 * s + fh;
             uint4 wf[TN], xf[TM];
 #pragma unroll
-            for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const uint4*>(wb + lds_off(wn * (TN * 32) + i * 32 + fr, c));
+            for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const uint4*>(tb + rd_w[i] + ((c ^ sw_w[i]) << 4));
 #pragma unroll
-            for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const uint4*>(xb + lds_off(wm * (TM * 32) + j * 32 + fr, c));
+            for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const uint4*>(tb + rd_x[j] + ((c ^ sw_x[j]) << 4));
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
@@ -234,9 +266,21 @@ static int launch_conv(const ConvP& p, hipStream_t stream) {
     q.ntiles = (p.N + BN - 1) / BN;
     const int grid = q.mtiles * q.ntiles;
     ProfScope prof(p.transposed ? PROF_CONV_DGRAD : PROF_CONV_FWD, 2.0 * (double)p.M * (double)p.N * (double)p.taps * (double)p.Cin, stream);
-    hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN>), dim3(grid), dim3(256), lds, stream, q);
+    const int mode = !p.fast ? 2 : (!p.transposed ? 0 : (p.stride == 1 ? 1 : 2));
+    if (mode == 0) hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 0>), dim3(grid), dim3(256), lds, stream, q);
+    else if (mode == 1) hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 1>), dim3(grid), dim3(256), lds, stream, q);
+    else hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 2>), dim3(grid), dim3(256), lds, stream, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "conv_gemm launch");
+    return PSG_OK;
+}
+
+template <typename T, int BM, int BN>
+static int set_conv_attrs() {
+    const int lds = 2 * (BM + BN) * 128;
+    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     return PSG_OK;
 }
 
@@ -246,14 +290,13 @@ using namespace psg;
 extern "C" {
 
 int psg_conv_init_attrs(void) {
-#define SET_LDS(K, BYTES) PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, BYTES))
-    SET_LDS((conv_gemm_kernel<float, 128, 128>), 2 * 256 * 128);
-    SET_LDS((conv_gemm_kernel<bf16_t, 128, 128>), 2 * 256 * 128);
-    SET_LDS((conv_gemm_kernel<float, 128, 64>), 2 * 192 * 128);
-    SET_LDS((conv_gemm_kernel<bf16_t, 128, 64>), 2 * 192 * 128);
-    SET_LDS((conv_gemm_kernel<float, 64, 64>), 2 * 128 * 128);
-    SET_LDS((conv_gemm_kernel<bf16_t, 64, 64>), 2 * 128 * 128);
-#undef SET_LDS
+    int rc;
+    if ((rc = set_conv_attrs<float, 128, 128>())) return rc;
+    if ((rc = set_conv_attrs<bf16_t, 128, 128>())) return rc;
+    if ((rc = set_conv_attrs<float, 128, 64>())) return rc;
+    if ((rc = set_conv_attrs<bf16_t, 128, 64>())) return rc;
+    if ((rc = set_conv_attrs<float, 64, 64>())) return rc;
+    if ((rc = set_conv_attrs<bf16_t, 64, 64>())) return rc;
     return PSG_OK;
 }
 
@@ -304,15 +347,30 @@ int psg_conv_fwd(const psg_conv_desc* d, psg_stream_t stream) {
     p.drop_scale = d->drop_p > 0.f ? 1.0f / (1.0f - d->drop_p) : 1.0f;
     p.drop_seed = d->drop_seed;
     p.mtiles = p.ntiles = 0;
+    {
+        const int64_t esz = d->dtype == PSG_BF16 ? 2 : 4;
+        const int64_t xb = (((int64_t)d->B * d->Hi * d->Wi - 1) * d->ldx + d->Cin) * esz;
+        const int64_t wb = (((int64_t)d->Cout - 1) * p.ldw + Kpad) * esz;
+        PSG_REQUIRE(xb < 0x7FFFFFF0ll && wb < 0x7FFFFFF0ll, PSG_ERR_SHAPE, "conv_fwd: operand extent >= 2 GiB (x %ld B, w %ld B)", (long)xb, (long)wb);
+        p.x_bytes = (uint32_t)xb; p.w_bytes = (uint32_t)wb;
+    }
 
-    // tile choice: keep >= ~2 waves of workgroups on the chip when the problem allows
+    // tile choice: maximise (useful fraction of the tile grid) x (chip fill of the last wave) x (tile efficiency)
     hipStream_t s = (hipStream_t)stream;
-    const int64_t t128 = ((M + 127) / 128) * ((d->Cout + 127) / 128);
-    const int64_t t12864 = ((M + 127) / 128) * ((d->Cout + 63) / 64);
-    const bool n_waste_128 = (d->Cout % 128) != 0 && (d->Cout % 128) <= 64;   // e.g. 320 -> last tile half empty
     int BM = 128, BN = 128;
-    if (d->Cout <= 64 || (n_waste_128 && t12864 >= 512) || t128 < 512) { BM = 128; BN = 64; }
-    if (t12864 < 512 && BN == 64) { BM = 64; BN = 64; }
+    {
+        const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+        const double eff[3] = {1.0, 0.78, 0.55};          // measured relative MFMA efficiency of the tile shapes
+        double best = -1.0;
+        for (int c = 0; c < 3; ++c) {
+            const double tiles = (double)((M + cand[c][0] - 1) / cand[c][0]) * (double)((d->Cout + cand[c][1] - 1) / cand[c][1]);
+            const double useful = (double)M * d->Cout / (tiles * cand[c][0] * cand[c][1]);
+            const double slots = 512.0;                    // 256 CUs x 2 resident workgroups
+            const double waves = ceil(tiles / slots);
+            const double score = useful * (tiles / (waves * slots)) * eff[c];
+            if (score > best) { best = score; BM = cand[c][0]; BN = cand[c][1]; }
+        }
+    }
     if (d->dtype == PSG_F32) {
         if (BM == 128 && BN == 128) return launch_conv<float, 128, 128>(p, s);
         if (BM == 128 && BN == 64) return launch_conv<float, 128, 64>(p, s);

@@ -24,6 +24,7 @@ struct WgP {
     int M, Q, taps;
     int rtiles, qtiles, splits, steps_per_split;   // steps of BKP pixels
     float inv_HoWo, inv_Wo;
+    uint32_t x_bytes, dy_bytes;
 };
 
 template <typename T> struct WgCfg;
@@ -70,24 +71,48 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
     int nsteps = total_steps - step0;
     if (nsteps > p.steps_per_split) nsteps = p.steps_per_split;
 
-    uint4 ga[NPASS], gb[NPASS];
-    auto load_tiles = [&](int step) {
-        const int mbase = (step0 + step) * BKP;
+    constexpr uint32_t OOB = 0x80000000u;          // extents are < 2 GiB (checked on the host)
+    constexpr int ESZ = (int)sizeof(T);
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, p.dy_bytes, 0x00020000);
+    // Per-row "odometer": (m, ho, wo, byte offsets) of each staged pixel row advance by BKP pixels per K step
+    // with adds / compares / selects only (no integer multiply or divide in the loop).
+    const int ldxB = (int)p.ldx * ESZ;
+    const int od_dB = BKP / HoWo, od_r1 = BKP - od_dB * HoWo, od_dH = od_r1 / p.Wo, od_dW = od_r1 - od_dH * p.Wo;   // uniform
+    const int SW = p.stride * ldxB, SH = p.stride * p.Wi * ldxB, SB = p.Hi * p.Wi * ldxB;
+    const int od_A0 = od_dW * SW + od_dH * SH + od_dB * SB, od_K1 = SH - p.Wo * SW, od_K2 = SB - p.Ho * SH;
+    const int a_step = BKP * (int)p.lddy * ESZ;
+    const int b_const = ((b_kh - p.pad) * p.Wi + (b_kw - p.pad)) * ldxB + b_ci * ESZ;
+    int r_m[NPASS], r_ho[NPASS], r_wo[NPASS], r_pix[NPASS], r_a[NPASS];
+#pragma unroll
+    for (int j = 0; j < NPASS; ++j) {
+        const int m = step0 * BKP + sr + RPP * j;
+        const int b = m / HoWo, rm = m - b * HoWo;
+        r_m[j] = m; r_ho[j] = rm / p.Wo; r_wo[j] = rm - r_ho[j] * p.Wo;
+        r_pix[j] = b * SB + r_ho[j] * SH + r_wo[j] * SW;
+        r_a[j] = (m * (int)p.lddy + a_co) * ESZ;
+    }
+    u32x4 ga[NPASS], gb[NPASS];
+    auto load_tiles = [&]() {          // loads the rows at the current odometer state, then advances it
 #pragma unroll
         for (int j = 0; j < NPASS; ++j) {
-            const int m = mbase + sr + RPP * j;
-            const bool m_ok = m < p.M;
-            ga[j] = (m_ok && a_ok) ? *reinterpret_cast<const uint4*>(dyg + (int64_t)m * p.lddy + a_co) : make_uint4(0, 0, 0, 0);
-            bool ok = m_ok && b_ok;
-            int64_t off = 0;
-            if (ok) {
-                const int b = fastdiv(m, HoWo, p.inv_HoWo), rm = m - b * HoWo;
-                const int ho = fastdiv(rm, p.Wo, p.inv_Wo), wo = rm - ho * p.Wo;
-                const int sh = ho * p.stride - p.pad + b_kh, sw = wo * p.stride - p.pad + b_kw;
-                ok = sh >= 0 && sw >= 0 && sh < p.Hi && sw < p.Wi;
-                off = (int64_t)((b * p.Hi + sh) * p.Wi + sw) * p.ldx + b_ci;
-            }
-            gb[j] = ok ? *reinterpret_cast<const uint4*>(xg + off) : make_uint4(0, 0, 0, 0);
+            const bool m_ok = r_m[j] < p.M;
+            const uint32_t aoff = (m_ok && a_ok) ? (uint32_t)r_a[j] : OOB;
+            const int sh = r_ho[j] * p.stride - p.pad + b_kh, sw = r_wo[j] * p.stride - p.pad + b_kw;
+            const bool ok = m_ok && b_ok && (unsigned)sh < (unsigned)p.Hi && (unsigned)sw < (unsigned)p.Wi;
+            const uint32_t boff = ok ? (uint32_t)(r_pix[j] + b_const) : OOB;
+            ga[j] = __builtin_amdgcn_raw_buffer_load_b128(yrs, aoff, 0, 0);
+            gb[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, boff, 0, 0);
+            // advance by BKP pixels
+            r_m[j] += BKP; r_a[j] += a_step;
+            int wo = r_wo[j] + od_dW;
+            const bool c1 = wo >= p.Wo;
+            wo -= c1 ? p.Wo : 0;
+            int ho = r_ho[j] + od_dH + (c1 ? 1 : 0);
+            const bool c2 = ho >= p.Ho;
+            ho -= c2 ? p.Ho : 0;
+            r_wo[j] = wo; r_ho[j] = ho;
+            r_pix[j] += od_A0 + (c1 ? od_K1 : 0) + (c2 ? od_K2 : 0);
         }
     };
     auto store_tiles = [&](int buf) {
@@ -95,8 +120,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
 #pragma unroll
         for (int j = 0; j < NPASS; ++j) {
             const int row = sr + RPP * j;
-            *reinterpret_cast<uint4*>(base + row * ROWB + sc * 16) = ga[j];
-            *reinterpret_cast<uint4*>(base + TILE_BYTES + row * ROWB + sc * 16) = gb[j];
+            *reinterpret_cast<u32x4*>(base + row * ROWB + sc * 16) = ga[j];
+            *reinterpret_cast<u32x4*>(base + TILE_BYTES + row * ROWB + sc * 16) = gb[j];
         }
     };
 
@@ -109,14 +134,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     if (nsteps > 0) {
-        load_tiles(0);
+        load_tiles();
         store_tiles(0);
     }
     __syncthreads();
 
     for (int st = 0; st < nsteps; ++st) {
         const int buf = st & 1;
-        if (st + 1 < nsteps) load_tiles(st + 1);
+        if (st + 1 < nsteps) load_tiles();
         const char* ab = smem + buf * 2 * TILE_BYTES;
         const char* bb = ab + TILE_BYTES;
         if constexpr (sizeof(T) == 2) {
@@ -270,6 +295,13 @@ int psg_conv_wgrad(const psg_wgrad_desc* d, psg_stream_t stream) {
     p.B = d->B; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
     p.ks = d->ksize; p.stride = d->stride; p.pad = d->pad;
     p.inv_HoWo = 1.0f / (float)(d->Ho * d->Wo); p.inv_Wo = 1.0f / (float)d->Wo;
+    {
+        const int64_t esz = d->dtype == PSG_BF16 ? 2 : 4;
+        const int64_t xb = (((int64_t)d->B * d->Hi * d->Wi - 1) * d->ldx + d->Cin) * esz;
+        const int64_t yb = (((int64_t)p.M - 1) * d->lddy + d->Cout) * esz;
+        PSG_REQUIRE(xb < 0x7FFFFFF0ll && yb < 0x7FFFFFF0ll, PSG_ERR_SHAPE, "wgrad: operand extent >= 2 GiB");
+        p.x_bytes = (uint32_t)xb; p.dy_bytes = (uint32_t)yb;
+    }
     const int grid = p.rtiles * p.qtiles * p.splits;
     hipStream_t s = (hipStream_t)stream;
     {
