@@ -346,30 +346,39 @@ __global__ void clip_scale_kernel(float* __restrict__ g, int64_t n, const float*
 template <typename T>
 __global__ void prep_weight_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd,
                                    int O, int I, int taps, int64_t kpf, int64_t kpd) {
+    // One workgroup per (32 co) x (32 ci) x taps tile: W is read ONCE, coalesced (32*taps contiguous floats per
+    // co row), transposed through LDS, and both prepared layouts are written in 64-byte runs.
+    __shared__ float t[32][32 * 9 + 1];
+    const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
+    const int nci = min(32, I - ci0), nco = min(32, O - co0);
+    const int run = nci * taps;
+    for (int e = threadIdx.x; e < nco * run; e += blockDim.x) {
+        const int r = e / run, c = e - r * run;
+        t[r][c] = w[((int64_t)(co0 + r) * I + ci0) * taps + c];
+    }
+    __syncthreads();
     if (wf) {
-        const int64_t n = (int64_t)O * kpf;
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-            const int64_t k = i % kpf;
-            const int64_t o = i / kpf;
-            float v = 0.f;
-            if (k < (int64_t)taps * I) {
-                const int tap = (int)(k / I), ci = (int)(k % I);
-                v = w[(o * I + ci) * taps + tap];
-            }
-            Elem<T>::st(wf + i, v);
+        for (int e = threadIdx.x; e < nco * taps * 32; e += blockDim.x) {
+            const int ci = e & 31, rt = e >> 5;
+            const int tap = rt % taps, r = rt / taps;
+            if (ci < nci) Elem<T>::st(wf + (int64_t)(co0 + r) * kpf + (int64_t)tap * I + ci0 + ci, t[r][ci * taps + tap]);
+        }
+        if (blockIdx.x == 0) {                         // zero the K padding of these rows
+            const int64_t k0 = (int64_t)taps * I, npad = kpf - k0;
+            for (int64_t e = threadIdx.x; e < nco * npad; e += blockDim.x)
+                Elem<T>::st(wf + (int64_t)(co0 + e / npad) * kpf + k0 + e % npad, 0.f);
         }
     }
     if (wd) {
-        const int64_t n = (int64_t)I * kpd;
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-            const int64_t k = i % kpd;
-            const int64_t ci = i / kpd;
-            float v = 0.f;
-            if (k < (int64_t)taps * O) {
-                const int tap = (int)(k / O), co = (int)(k % O);
-                v = w[((int64_t)co * I + ci) * taps + tap];
-            }
-            Elem<T>::st(wd + i, v);
+        for (int e = threadIdx.x; e < nci * taps * 32; e += blockDim.x) {
+            const int r = e & 31, ct = e >> 5;
+            const int tap = ct % taps, ci = ct / taps;
+            if (r < nco) Elem<T>::st(wd + (int64_t)(ci0 + ci) * kpd + (int64_t)tap * O + co0 + r, t[r][ci * taps + tap]);
+        }
+        if (blockIdx.y == 0) {
+            const int64_t k0 = (int64_t)taps * O, npad = kpd - k0;
+            for (int64_t e = threadIdx.x; e < nci * npad; e += blockDim.x)
+                Elem<T>::st(wd + (int64_t)(ci0 + e / npad) * kpd + k0 + e % npad, 0.f);
         }
     }
 }
@@ -649,10 +658,8 @@ int psg_prep_weight(const float* w, void* wf, void* wd, int O, int I, int ksize,
     PSG_REQUIRE(O > 0 && I > 0 && (ksize == 1 || ksize == 3), PSG_ERR_SHAPE, "prep_weight: O=%d I=%d k=%d", O, I, ksize);
     const int taps = ksize * ksize;
     const int64_t kpf = psg_kpad((int64_t)taps * I, dtype), kpd = psg_kpad((int64_t)taps * O, dtype);
-    int64_t n = 0;
-    if (wf) n = (int64_t)O * kpf;
-    if (wd && (int64_t)I * kpd > n) n = (int64_t)I * kpd;
-    const int g = grid_for(n, 256, 8192);
+    PSG_REQUIRE((O + 31) / 32 <= 65535, PSG_ERR_SHAPE, "prep_weight: O=%d too large", O);
+    const dim3 g((I + 31) / 32, (O + 31) / 32);
     DISPATCH_DTYPE(dtype,
         hipLaunchKernelGGL(prep_weight_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, w, (float*)wf, (float*)wd, O, I, taps, kpf, kpd),
         hipLaunchKernelGGL(prep_weight_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)wf, (bf16_t*)wd, O, I, taps, kpf, kpd));

@@ -36,10 +36,6 @@ class BucketedAllReduce:
         self._pending = [0] * len(self.buckets)
         self._works = []
         self._stream = torch.cuda.Stream() if self.overlap else None
-        self._hooks = []
-        if self.world > 1 and self.overlap:
-            for i, p in enumerate(params):
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
         self.reset()
 
     def reset(self):
@@ -47,13 +43,14 @@ class BucketedAllReduce:
             self._pending[b] = len(mem)
         self._works = []
 
-    def _make_hook(self, i):
-        def hook(_p):
-            b = self._bucket_of[i]
-            self._pending[b] -= 1
-            if self._pending[b] == 0:
-                self._launch(b)
-        return hook
+    def on_ready(self, i):
+        """Called (by the gradient sink) when parameter i's gradient is final for this step."""
+        if self.world == 1 or not self.overlap:
+            return
+        b = self._bucket_of[i]
+        self._pending[b] -= 1
+        if self._pending[b] == 0:
+            self._launch(b)
 
     def _launch(self, b):
         s, e, _ = self.buckets[b]

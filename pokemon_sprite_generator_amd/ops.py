@@ -87,6 +87,47 @@ class WeightCache:
         return wf, wd
 
 
+class GradSink:
+    """Parameter -> persistent fp32 gradient view (optim.GradArena).  When a parameter is registered, the
+    backward kernels write (first use in a step) or accumulate (later uses) its gradient straight into the
+    view and autograd gets None: no per-step zero-fill and no AccumulateGrad read-modify-write pass over
+    640 M values.  `on_ready(index)` is how the data-parallel reducer learns a gradient is final."""
+    _map = {}
+
+    class Entry:
+        __slots__ = ("view", "written", "index", "on_ready", "param")
+
+    @classmethod
+    def register(cls, param, view, index, on_ready=None):
+        e = cls.Entry()
+        e.view, e.written, e.index, e.on_ready, e.param = view, False, index, on_ready, param
+        cls._map[id(param)] = e
+
+    @classmethod
+    def unregister_all(cls):
+        cls._map.clear()
+
+    @classmethod
+    def begin_step(cls):
+        for e in cls._map.values():
+            e.written = False
+
+    @classmethod
+    def get(cls, param):
+        e = cls._map.get(id(param))
+        return e if (e is not None and e.param is param) else None
+
+    @classmethod
+    def done(cls, e):
+        e.written = True
+        if e.on_ready is not None:
+            e.on_ready(e.index)
+
+    @classmethod
+    def unwritten(cls):
+        return [e for e in cls._map.values() if not e.written]
+
+
 def _conv_launch(lib, dtype, x, ldx, w, ldw, y, ldy, geom, Cin, Cout, transposed=False, bias=None, rowadd=None,
                  residual=None, ld_res=0, preact=None, dact_u=None, ld_dact=0, act=ACT_NONE, alpha=1.0, drop_p=0.0, seed=0):
     B, Hi, Wi, Ho, Wo, ks, stride, pad = geom
@@ -125,12 +166,26 @@ def _wgrad_launch(lib, dtype, x, ldx, dy, lddy, dw, geom, Cin, Cout, accumulate=
     check(lib.psg_conv_wgrad(C.byref(d), stream_ptr()), "psg_conv_wgrad")
 
 
-def _colsum(lib, a, lda, R, groups, cols, dtype, out_dtype, keep2d=False):
-    out = torch.empty((groups, cols) if keep2d or groups > 1 else (cols,), dtype=out_dtype, device=a.device)
+def _colsum(lib, a, lda, R, groups, cols, dtype, out_dtype, keep2d=False, out=None, accumulate=False):
+    if out is None:
+        out = torch.empty((groups, cols) if keep2d or groups > 1 else (cols,), dtype=out_dtype, device=a.device)
     need = lib.psg_colsum_workspace_bytes(R, groups, cols)
     ws = _lib.workspace(need, a.device)
-    check(lib.psg_colsum(ptr(a), lda, ptr(out), cols, R, groups, cols, dtype_code(dtype), dtype_code(out_dtype), 0,
+    check(lib.psg_colsum(ptr(a), lda, ptr(out), cols, R, groups, cols, dtype_code(dtype), dtype_code(out_dtype), int(accumulate),
                          ptr(ws), ws.numel(), stream_ptr()), "psg_colsum")
+    return out
+
+
+def _param_grad(param, compute):
+    """Run `compute(out, accumulate)` for a parameter gradient: into the registered sink (returns None for
+    autograd) or into a fresh tensor (returned)."""
+    e = GradSink.get(param)
+    if e is not None:
+        compute(e.view, e.written)
+        GradSink.done(e)
+        return None
+    out = torch.empty_like(param)
+    compute(out, False)
     return out
 
 
@@ -172,6 +227,7 @@ class _ConvFn(torch.autograd.Function):
         _conv_launch(lib, dtype, xr, ldx, wf, 0, y, Cout, geom, Cin, Cout, bias=bias, rowadd=ra, residual=res_r, ld_res=ld_res,
                      preact=preact, act=act, alpha=alpha, drop_p=drop_p, seed=seed)
         ctx.save_for_backward(xr, weight, preact)
+        ctx.bias_param, ctx.weight_param = bias, weight
         ctx.meta = (geom, Cin, Cout, ldx, act, alpha, drop_p, seed, bias is not None, rowadd is not None, residual is not None, tuple(x.shape), wd)
         return y
 
@@ -201,10 +257,9 @@ class _ConvFn(torch.autograd.Function):
             tgeom = (B, Ho, Wo, Hi, Wi, ks, stride, pad)     # gather source = dY grid, result = input grid
             _conv_launch(lib, dtype, g, ldg, wd, 0, dx, Cin, tgeom, Cout, Cin, transposed=True)
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(weight)
-            _wgrad_launch(lib, dtype, xr, ldx, g, ldg, dw, geom, Cin, Cout)
+            dw = _param_grad(ctx.weight_param, lambda out, acc: _wgrad_launch(lib, dtype, xr, ldx, g, ldg, out, geom, Cin, Cout, accumulate=acc))
         if has_bias and ctx.needs_input_grad[2]:
-            db = _colsum(lib, g, ldg, M, 1, Cout, dtype, torch.float32)
+            db = _param_grad(ctx.bias_param, lambda out, acc: _colsum(lib, g, ldg, M, 1, Cout, dtype, torch.float32, out=out, accumulate=acc))
         if has_ra and ctx.needs_input_grad[3]:
             dra = _colsum(lib, g, ldg, Ho * Wo, B, Cout, dtype, dtype, keep2d=True)
         return dx, dw, db, dra, d_res, None, None, None, None, None
@@ -240,6 +295,7 @@ class _CrossInProjFn(torch.autograd.Function):
         _conv_launch(lib, dtype, xr, ldx, wf.data_ptr(), 0, q, E, (Mq, 1, 1, 1, 1, 1, 1, 0), E, E, bias=bias[:E])
         _conv_launch(lib, dtype, tr, ldt, wf.data_ptr() + E * kp * esz, 0, kv, 2 * E, (Mk, 1, 1, 1, 1, 1, 1, 0), E, 2 * E, bias=bias[E:])
         ctx.save_for_backward(xr, tr, weight)
+        ctx.bias_param, ctx.weight_param = bias, weight
         ctx.meta = (E, ldx, ldt, Mq, Mk, tuple(xn.shape), tuple(tp.shape), wd, wf)
         return q, kv
 
@@ -263,12 +319,15 @@ class _CrossInProjFn(torch.autograd.Function):
             dtp = torch.empty(ts, dtype=dtype, device=dq.device)
             _conv_launch(lib, dtype, dkr, lddk, wd.data_ptr() + E * esz, kpd, dtp, E, (Mk, 1, 1, 1, 1, 1, 1, 0), 2 * E, E, transposed=True)
         if ctx.needs_input_grad[2]:
-            dw = torch.empty_like(weight)
-            _wgrad_launch(lib, dtype, xr, ldx, dqr, lddq, dw[:E], (Mq, 1, 1, 1, 1, 1, 1, 0), E, E)
-            _wgrad_launch(lib, dtype, tr, ldt, dkr, lddk, dw[E:], (Mk, 1, 1, 1, 1, 1, 1, 0), E, 2 * E)
+            def wg(out, acc):
+                _wgrad_launch(lib, dtype, xr, ldx, dqr, lddq, out[:E], (Mq, 1, 1, 1, 1, 1, 1, 0), E, E, accumulate=acc)
+                _wgrad_launch(lib, dtype, tr, ldt, dkr, lddk, out[E:], (Mk, 1, 1, 1, 1, 1, 1, 0), E, 2 * E, accumulate=acc)
+            dw = _param_grad(ctx.weight_param, wg)
         if ctx.needs_input_grad[3]:
-            db = torch.cat([_colsum(lib, dqr, lddq, Mq, 1, E, dtype, torch.float32),
-                            _colsum(lib, dkr, lddk, Mk, 1, 2 * E, dtype, torch.float32)])
+            def bg(out, acc):
+                _colsum(lib, dqr, lddq, Mq, 1, E, dtype, torch.float32, out=out[:E], accumulate=acc)
+                _colsum(lib, dkr, lddk, Mk, 1, 2 * E, dtype, torch.float32, out=out[E:], accumulate=acc)
+            db = _param_grad(ctx.bias_param, bg)
         return dxn, dtp, dw, db
 
 
@@ -292,6 +351,7 @@ class _GroupNormFn(torch.autograd.Function):
         check(lib.psg_groupnorm_fwd(ptr(xr), ldx, ptr(y), Cc, ptr(gamma), ptr(beta), ptr(stats[0]), ptr(stats[1]), B, HW, Cc, groups,
                                     float(eps), int(silu), dtype_code(dtype), stream_ptr()), "psg_groupnorm_fwd")
         ctx.save_for_backward(xr, gamma, beta, stats)
+        ctx.gamma_param, ctx.beta_param = gamma, beta
         ctx.meta = (B, HW, Cc, groups, silu, ldx, tuple(x.shape))
         return y
 
@@ -303,12 +363,22 @@ class _GroupNormFn(torch.autograd.Function):
         dtype = dy.dtype
         dyr, lddy = _rows(dy)
         dx = torch.empty(shape, dtype=dtype, device=dy.device)
-        dg = torch.empty(Cc, dtype=torch.float32, device=dy.device)
-        db = torch.empty(Cc, dtype=torch.float32, device=dy.device)
+        eg, eb = GradSink.get(ctx.gamma_param), GradSink.get(ctx.beta_param)
+        sink = eg is not None and eb is not None and eg.written == eb.written
+        if sink:
+            dg, db, acc = eg.view, eb.view, eg.written
+        else:
+            dg = torch.empty(Cc, dtype=torch.float32, device=dy.device)
+            db = torch.empty(Cc, dtype=torch.float32, device=dy.device)
+            acc = False
         ws = _lib.workspace(lib.psg_groupnorm_bwd_workspace_bytes(B, Cc), dy.device)
         check(lib.psg_groupnorm_bwd(ptr(dyr), lddy, ptr(xr), ldx, ptr(gamma), ptr(beta), ptr(stats[0]), ptr(stats[1]), ptr(dx), Cc,
-                                    ptr(dg), ptr(db), B, HW, Cc, groups, int(silu), 0, dtype_code(dtype), ptr(ws), stream_ptr()),
+                                    ptr(dg), ptr(db), B, HW, Cc, groups, int(silu), int(acc), dtype_code(dtype), ptr(ws), stream_ptr()),
               "psg_groupnorm_bwd")
+        if sink:
+            GradSink.done(eg)
+            GradSink.done(eb)
+            return dx, None, None, None, None, None
         return dx, dg, db, None, None, None
 
 

@@ -1,19 +1,21 @@
 """Gradient arena + fused clip/AdamW (reference: improved_diffusion_trainer.py:277-283, 399-413).
 
 GradArena keeps every parameter gradient in ONE flat fp32 buffer (p.grad are
-persistent views), so the global L2 norm is one deterministic reduction
-(psg_sumsq_f32) instead of 478 `.item()` syncs, clip + AdamW is one kernel
-(psg_adamw_f32) and the data-parallel all-reduce runs on large flat slices.
+persistent views) and registers each view as a GradSink: the wgrad / column-sum
+/ GroupNorm-backward kernels write gradients straight into it.  The global L2
+norm is then one deterministic reduction (psg_sumsq_f32) instead of 478
+`.item()` syncs, clip + AdamW is fused (psg_adamw_f32) and the data-parallel
+all-reduce runs on large flat slices.
 """
 import torch
 
 from . import _lib
 from ._lib import check, ptr, stream_ptr
-from .ops import WeightCache
+from .ops import GradSink, WeightCache
 
 
 class GradArena:
-    def __init__(self, params):
+    def __init__(self, params, on_ready=None):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("GradArena: no trainable parameters")
@@ -25,15 +27,32 @@ class GradArena:
             off += (p.numel() + 3) // 4 * 4          # keep every view 16-byte aligned
         self.numel = off
         self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
-        for p, o in zip(self.params, self.offsets):
-            p.grad = self.flat[o:o + p.numel()].view_as(p)
         self.normsq = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.on_ready = on_ready
+        self.views = []
+        GradSink.unregister_all()
+        for i, (p, o) in enumerate(zip(self.params, self.offsets)):
+            v = self.flat[o:o + p.numel()].view_as(p)
+            self.views.append(v)
+            p.grad = v
+            GradSink.register(p, v, i, self._ready)
+
+    def _ready(self, index):
+        if self.on_ready is not None:
+            self.on_ready(index)
 
     def zero(self):
-        self.flat.zero_()
-        for p, o in zip(self.params, self.offsets):      # re-attach if someone set grads to None
-            if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * o:
-                p.grad = self.flat[o:o + p.numel()].view_as(p)
+        """Start of a step: nothing is memset — every sink is overwritten by its first gradient kernel."""
+        GradSink.begin_step()
+        for p, v in zip(self.params, self.views):       # re-attach if someone set grads to None
+            if p.grad is not v:
+                p.grad = v
+
+    def finalize(self):
+        """After backward: parameters that received no gradient this step get an explicit zero."""
+        for e in GradSink.unwritten():
+            e.view.zero_()
+            GradSink.done(e)
 
     def grad_norm_sq(self):
         """Device scalar sum(g^2) over all parameters (padding is zero)."""
@@ -52,7 +71,7 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
 
     @torch.no_grad()
-    def step(self, normsq=None, max_norm=0.0, skip_flag=None):
+    def step(self, normsq=None, max_norm=0.0, skip_flag=None, grad_scale=1.0):
         lib = None
         for group in self.param_groups:
             b1, b2 = group["betas"]

@@ -55,7 +55,8 @@ class DiffusionStepper:
         if self.device.type != "cuda":
             raise _lib.PsgError("DiffusionStepper needs the U-Net on a GPU (HIP path only)")
         self.lib = _lib.init(self.device.index if self.device.index is not None else torch.cuda.current_device())
-        self.arena = GradArena(unet.parameters())
+        self.reducer = None
+        self.arena = GradArena(unet.parameters(), on_ready=lambda i: self.reducer.on_ready(i) if self.reducer is not None else None)
         # Adam (non-decoupled decay) is torch's when asked for (:285-291); AdamW is the fused kernel (:277-283)
         if optimizer_type == "adamw":
             self.optimizer = FusedAdamW(self.arena.params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
@@ -91,6 +92,7 @@ class DiffusionStepper:
         eps_hat = self.unet(noisy, t, text_emb)                                                     # :381
         loss, dpred = self.smooth_l1(eps_hat, noise)                                                # :388
         eps_hat.backward(dpred)                                                                     # :396
+        self.arena.finalize()
         if self.reducer is not None:
             self.reducer.finish()
             torch.distributed.all_reduce(self.flag, op=torch.distributed.ReduceOp.MAX)              # all ranks skip together

@@ -187,6 +187,7 @@ def test_train_step_golden(psg, golden, full_unets):
     eps = u(noisy, t.to(DEV), text.to(DEV))
     loss, dpred = st.smooth_l1(eps, noise.to(DEV))
     eps.backward(dpred)
+    st.arena.finalize()
     gn = float(st.arena.grad_norm_sq().sqrt().item())
     assert maxrel(eps, torch.from_numpy(g[name + "_eps"])) < FP32_TOL
     assert abs(float(loss.item()) - float(g[name + "_loss"][0])) / float(g[name + "_loss"][0]) < 1e-4
