@@ -117,7 +117,8 @@ int psg_add(const void* a, int64_t lda, const void* b, int64_t ldb, void* y, int
  * ------------------------------------------------------------------------- */
 int psg_groupnorm_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, const float* gamma,
                       const float* beta, float* mean, float* rstd, int B, int HW, int C, int G,
-                      float eps, int silu, int dtype, psg_stream_t stream);
+                      float eps, int silu, int dtype, void* ws, psg_stream_t stream);
+int64_t psg_groupnorm_fwd_workspace_bytes(int B, int G);
 /* dx (may alias dy), dgamma/dbeta fp32 [C] (overwritten, or accumulated if accumulate!=0).
  * ws: >= psg_groupnorm_bwd_workspace_bytes(B,C) bytes. */
 int psg_groupnorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* gamma,

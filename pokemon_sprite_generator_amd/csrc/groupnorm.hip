@@ -1,190 +1,227 @@
-// GroupNorm (+ fused SiLU) forward / backward, channels-last [B, HW, C].
-// One workgroup per (sample, group): the group's HW x Cg slab (<= 58 KB fp32 at
-// the U-Net's shapes) is staged ONCE into LDS, statistics are wave-shuffle /
-// LDS reductions, and the normalised output is written from LDS, so HBM traffic
-// is the algorithmic minimum: 1 read + 1 write per element forward, 2 reads +
-// 1 write backward.  Roofline: HBM.
+// GroupNorm (+ fused SiLU) forward / backward, channels-last [B, HW, C].  Roofline: HBM.
+//
+// Every pass streams whole pixel rows with 16-byte vectors per lane (a thread owns one fixed
+// 16-byte channel chunk and walks pixels), so loads/stores are fully coalesced for every
+// channels-per-group value (10, 20, 40, 80: a chunk may straddle two groups - handled per
+// element).  Work is split over (sample, pixel-split) workgroups to fill the chip:
+//   forward : stats kernel -> per-(b, split, group) partial (sum, sum of squares)
+//             apply kernel -> combines the partials (double), writes mean/rstd, normalises
+//   backward: reduce kernel -> per-(b, split, channel) partial (sum dz*xhat, sum dz)
+//             apply kernel  -> combines them per sample, forms the two group sums, writes dx
+//             param kernel  -> dgamma/dbeta over the batch (fixed order)
+// All reductions are fixed-order (LDS trees, no float atomics): results are run-to-run identical.
+// Traffic: x read twice + y written (forward), x and dy read twice + dx written (backward); the
+// second read of a <=1 MB per-sample slab is served from L2 / Infinity Cache.
 #include "psg_common.h"
 
 namespace psg {
 
-constexpr int GN_THREADS = 256;
-constexpr int GN_LDS_ELEMS = 16384;  // slab cap held in LDS (elements of T)
+constexpr int GN_MAXSPLIT = 8;
 
-// element e in [0, HW*Cg) -> (pixel, channel-in-group); Cg even, 2 elements per access
+struct GnP {
+    const void *x, *dy; void *y, *dx;
+    const float *gamma, *beta; float *mean, *rstd, *ws, *dgamma, *dbeta;
+    int64_t ldx, ldy, lddy, lddx;
+    int B, HW, C, G, Cg, CC, PP, NS, pps;   // CC chunks per row, PP pixel lanes, NS splits, pps pixels per split
+    float eps; int silu, accumulate;
+};
+
+template <typename T> struct Vec;
+template <> struct Vec<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void ld(const float* p, float* v) { f32x4 t = *reinterpret_cast<const f32x4*>(p); v[0] = t[0]; v[1] = t[1]; v[2] = t[2]; v[3] = t[3]; }
+    static __device__ __forceinline__ void st(float* p, const float* v) { f32x4 t = {v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(p) = t; }
+};
+template <> struct Vec<bf16_t> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void ld(const bf16_t* p, float* v) {
+        bf16x8 t = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+    }
+    static __device__ __forceinline__ void st(bf16_t* p, const float* v) {
+        bf16x8 t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) t[e] = (bf16_t)v[e];
+        *reinterpret_cast<bf16x8*>(p) = t;
+    }
+};
+
+// ---------------------------------------------------------------- forward: partial statistics
 template <typename T>
-__device__ __forceinline__ void ld2(const T* p, float& a, float& b);
-template <> __device__ __forceinline__ void ld2<float>(const float* p, float& a, float& b) {
-    float2 v = *reinterpret_cast<const float2*>(p); a = v.x; b = v.y;
+__global__ void gn_stats_kernel(const GnP p) {
+    constexpr int N = Vec<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // [PP][C][2]
+    const int b = blockIdx.x / p.NS, split = blockIdx.x - b * p.NS;
+    const int c = threadIdx.x % p.CC, pl = threadIdx.x / p.CC;
+    const int p0 = split * p.pps, p1 = min(p.HW, p0 + p.pps);
+    const T* xb = reinterpret_cast<const T*>(p.x) + (int64_t)b * p.HW * p.ldx + c * N;
+    float s[N], q[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) { s[e] = 0.f; q[e] = 0.f; }
+    for (int px = p0 + pl; px < p1; px += p.PP) {
+        float v[N];
+        Vec<T>::ld(xb + (int64_t)px * p.ldx, v);
+#pragma unroll
+        for (int e = 0; e < N; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
+    }
+    float* row = sm + (int64_t)pl * p.C * 2;
+#pragma unroll
+    for (int e = 0; e < N; ++e) { row[(c * N + e) * 2] = s[e]; row[(c * N + e) * 2 + 1] = q[e]; }
+    __syncthreads();
+    if (threadIdx.x < p.G) {
+        const int g = threadIdx.x;
+        float a0 = 0.f, a1 = 0.f;
+        for (int l = 0; l < p.PP; ++l)
+            for (int ch = g * p.Cg; ch < (g + 1) * p.Cg; ++ch) { a0 += sm[((int64_t)l * p.C + ch) * 2]; a1 += sm[((int64_t)l * p.C + ch) * 2 + 1]; }
+        float* o = p.ws + ((int64_t)blockIdx.x * p.G + g) * 2;
+        o[0] = a0; o[1] = a1;
+    }
 }
-template <> __device__ __forceinline__ void ld2<bf16_t>(const bf16_t* p, float& a, float& b) {
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-    bf16x2 v = *reinterpret_cast<const bf16x2*>(p); a = (float)v[0]; b = (float)v[1];
-}
+
+// ---------------------------------------------------------------- forward: apply
 template <typename T>
-__device__ __forceinline__ void st2(T* p, float a, float b);
-template <> __device__ __forceinline__ void st2<float>(float* p, float a, float b) {
-    *reinterpret_cast<float2*>(p) = make_float2(a, b);
-}
-template <> __device__ __forceinline__ void st2<bf16_t>(bf16_t* p, float a, float b) {
-    typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-    bf16x2 v = {(bf16_t)a, (bf16_t)b};
-    *reinterpret_cast<bf16x2*>(p) = v;
-}
-
-template <typename T>
-__global__ __launch_bounds__(GN_THREADS) void gn_fwd_kernel(
-    const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy, const float* __restrict__ gamma,
-    const float* __restrict__ beta, float* __restrict__ mean_out, float* __restrict__ rstd_out, int HW, int C,
-    int G, float eps, int silu) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    T* slab = reinterpret_cast<T*>(smem_raw);
-    __shared__ float red[16];
-    const int b = blockIdx.x / G, g = blockIdx.x % G;
-    const int Cg = C / G, half = Cg >> 1;
-    const int npair = HW * half;
-    const bool in_lds = (HW * Cg) <= GN_LDS_ELEMS;
-    const float inv_half = 1.0f / (float)half;
-    const T* xb = x + (int64_t)b * HW * ldx + g * Cg;
-    T* yb = y + (int64_t)b * HW * ldy + g * Cg;
-
-    // pass 1: load (+stage), sum
-    float s = 0.f;
-    for (int e = threadIdx.x; e < npair; e += GN_THREADS) {
-        const int p = fastdiv(e, half, inv_half), cv = e - p * half;
-        float a, c;
-        ld2<T>(xb + (int64_t)p * ldx + 2 * cv, a, c);
-        if (in_lds) st2<T>(slab + 2 * e, a, c);
-        s += a + c;
-    }
-    const float n = (float)(HW * Cg);
-    const float mean = block_sum(s, red) / n;
-    // pass 2: variance about the mean (biased)
-    float q = 0.f;
-    for (int e = threadIdx.x; e < npair; e += GN_THREADS) {
-        float a, c;
-        if (in_lds) ld2<T>(slab + 2 * e, a, c);
-        else { const int p = fastdiv(e, half, inv_half), cv = e - p * half; ld2<T>(xb + (int64_t)p * ldx + 2 * cv, a, c); }
-        a -= mean; c -= mean;
-        q += a * a + c * c;
-    }
-    const float var = block_sum(q, red) / n;
-    const float rstd = rsqrtf(var + eps);
-    if (threadIdx.x == 0) { mean_out[blockIdx.x] = mean; rstd_out[blockIdx.x] = rstd; }
-    // pass 3: normalise, affine, SiLU
-    for (int e = threadIdx.x; e < npair; e += GN_THREADS) {
-        const int p = fastdiv(e, half, inv_half), cv = e - p * half;
-        float a, c;
-        if (in_lds) ld2<T>(slab + 2 * e, a, c);
-        else ld2<T>(xb + (int64_t)p * ldx + 2 * cv, a, c);
-        const int ch = g * Cg + 2 * cv;
-        a = (a - mean) * rstd * gamma[ch] + beta[ch];
-        c = (c - mean) * rstd * gamma[ch + 1] + beta[ch + 1];
-        if (silu) { a = silu_f(a); c = silu_f(c); }
-        st2<T>(yb + (int64_t)p * ldy + 2 * cv, a, c);
-    }
-}
-
-// backward: dx, and per-(b, channel) partials of dgamma / dbeta into ws[2][B][C]
-template <typename T>
-__global__ __launch_bounds__(GN_THREADS) void gn_bwd_kernel(
-    const T* __restrict__ dy, int64_t lddy, const T* __restrict__ x, int64_t ldx, const float* __restrict__ gamma,
-    const float* __restrict__ beta, const float* __restrict__ mean_in, const float* __restrict__ rstd_in,
-    T* __restrict__ dx, int64_t lddx, float* __restrict__ ws, int B, int HW, int C, int G, int silu) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    __shared__ float red[16];
-    __shared__ float chan_part[2][GN_THREADS];
-    const int b = blockIdx.x / G, g = blockIdx.x % G;
-    const int Cg = C / G, half = Cg >> 1;
-    const int npair = HW * half;
-    const int nel = HW * Cg;
-    const bool in_lds = nel <= GN_LDS_ELEMS;
-    T* sx = reinterpret_cast<T*>(smem_raw);
-    T* sd = sx + (in_lds ? ((nel + 7) & ~7) : 0);
-    const float inv_half = 1.0f / (float)half;
-    const T* xb = x + (int64_t)b * HW * ldx + g * Cg;
-    const T* dyb = dy + (int64_t)b * HW * lddy + g * Cg;
-    T* dxb = dx + (int64_t)b * HW * lddx + g * Cg;
-    const float mean = mean_in[blockIdx.x], rstd = rstd_in[blockIdx.x];
-
-    // pass A: stage x, dy; s1 = sum(dxhat), s2 = sum(dxhat * xhat)
-    float s1 = 0.f, s2 = 0.f;
-    for (int e = threadIdx.x; e < npair; e += GN_THREADS) {
-        const int p = fastdiv(e, half, inv_half), cv = e - p * half;
-        float xa, xc, da, dc;
-        ld2<T>(xb + (int64_t)p * ldx + 2 * cv, xa, xc);
-        ld2<T>(dyb + (int64_t)p * lddy + 2 * cv, da, dc);
-        if (in_lds) { st2<T>(sx + 2 * e, xa, xc); st2<T>(sd + 2 * e, da, dc); }
-        const int ch = g * Cg + 2 * cv;
-        const float ga = gamma[ch], gc = gamma[ch + 1];
-        const float ha = (xa - mean) * rstd, hc = (xc - mean) * rstd;
-        if (silu) { da *= silu_grad(ha * ga + beta[ch]); dc *= silu_grad(hc * gc + beta[ch + 1]); }
-        s1 += da * ga + dc * gc;
-        s2 += da * ga * ha + dc * gc * hc;
-    }
-    const float n = (float)nel;
-    s1 = block_sum(s1, red) / n;
-    s2 = block_sum(s2, red) / n;
-
-    // pass B: dx = rstd * (dxhat - s1 - xhat * s2)
-    for (int e = threadIdx.x; e < npair; e += GN_THREADS) {
-        const int p = fastdiv(e, half, inv_half), cv = e - p * half;
-        float xa, xc, da, dc;
-        if (in_lds) { ld2<T>(sx + 2 * e, xa, xc); ld2<T>(sd + 2 * e, da, dc); }
-        else { ld2<T>(xb + (int64_t)p * ldx + 2 * cv, xa, xc); ld2<T>(dyb + (int64_t)p * lddy + 2 * cv, da, dc); }
-        const int ch = g * Cg + 2 * cv;
-        const float ga = gamma[ch], gc = gamma[ch + 1];
-        const float ha = (xa - mean) * rstd, hc = (xc - mean) * rstd;
-        if (silu) { da *= silu_grad(ha * ga + beta[ch]); dc *= silu_grad(hc * gc + beta[ch + 1]); }
-        const float ra = rstd * (da * ga - s1 - ha * s2);
-        const float rc = rstd * (dc * gc - s1 - hc * s2);
-        st2<T>(dxb + (int64_t)p * lddx + 2 * cv, ra, rc);   // dx may alias dy: this element was consumed above
-    }
-
-    // pass C: per-channel sums over HW (deterministic): P threads per channel, then combine
-    if (Cg <= GN_THREADS) {
-        const int P = GN_THREADS / Cg;               // partial sums per channel
-        const int c = threadIdx.x % Cg, part = threadIdx.x / Cg;
-        float ag = 0.f, ab = 0.f;
-        if (part < P) {
-            const int ch = g * Cg + c;
-            const float gch = gamma[ch], bch = beta[ch];
-            for (int p = part; p < HW; p += P) {
-                float xv, dv;
-                if (in_lds) { xv = Elem<T>::ld(sx + p * Cg + c); dv = Elem<T>::ld(sd + p * Cg + c); }
-                else { xv = Elem<T>::ld(xb + (int64_t)p * ldx + c); dv = Elem<T>::ld(dyb + (int64_t)p * lddy + c); }
-                const float h = (xv - mean) * rstd;
-                if (silu) dv *= silu_grad(h * gch + bch);
-                ag += dv * h;
-                ab += dv;
-            }
+__global__ void gn_apply_kernel(const GnP p) {
+    constexpr int N = Vec<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // [G][2] mean, rstd
+    const int b = blockIdx.x / p.NS, split = blockIdx.x - b * p.NS;
+    if (threadIdx.x < p.G) {
+        const int g = threadIdx.x;
+        double a0 = 0.0, a1 = 0.0;
+        for (int s2 = 0; s2 < p.NS; ++s2) {
+            const float* o = p.ws + ((int64_t)(b * p.NS + s2) * p.G + g) * 2;
+            a0 += (double)o[0]; a1 += (double)o[1];
         }
-        __syncthreads();
-        chan_part[0][threadIdx.x] = ag;
-        chan_part[1][threadIdx.x] = ab;
-        __syncthreads();
-        if (threadIdx.x < Cg) {
-            float tg = 0.f, tb = 0.f;
-            for (int q = 0; q < P; ++q) { tg += chan_part[0][q * Cg + threadIdx.x]; tb += chan_part[1][q * Cg + threadIdx.x]; }
-            const int ch = g * Cg + threadIdx.x;
-            ws[(int64_t)b * C + ch] = tg;
-            ws[(int64_t)B * C + (int64_t)b * C + ch] = tb;
+        const double n = (double)p.HW * p.Cg;
+        const double mean = a0 / n;
+        double var = a1 / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)p.eps));
+        sm[g * 2] = (float)mean; sm[g * 2 + 1] = rstd;
+        if (split == 0) { p.mean[b * p.G + g] = (float)mean; p.rstd[b * p.G + g] = rstd; }
+    }
+    __syncthreads();
+    const int c = threadIdx.x % p.CC, pl = threadIdx.x / p.CC;
+    float sc[N], sh[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        const int ch = c * N + e, g = ch / p.Cg;
+        const float rs = sm[g * 2 + 1] * p.gamma[ch];
+        sc[e] = rs; sh[e] = p.beta[ch] - sm[g * 2] * rs;
+    }
+    const int p0 = split * p.pps, p1 = min(p.HW, p0 + p.pps);
+    const T* xb = reinterpret_cast<const T*>(p.x) + (int64_t)b * p.HW * p.ldx + c * N;
+    T* yb = reinterpret_cast<T*>(p.y) + (int64_t)b * p.HW * p.ldy + c * N;
+    for (int px = p0 + pl; px < p1; px += p.PP) {
+        float v[N];
+        Vec<T>::ld(xb + (int64_t)px * p.ldx, v);
+#pragma unroll
+        for (int e = 0; e < N; ++e) { v[e] = v[e] * sc[e] + sh[e]; if (p.silu) v[e] = silu_f(v[e]); }
+        Vec<T>::st(yb + (int64_t)px * p.ldy, v);
+    }
+}
+
+// ---------------------------------------------------------------- backward: per-channel partials
+template <typename T>
+__global__ void gn_bwd_reduce_kernel(const GnP p) {
+    constexpr int N = Vec<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // [PP][C][2]
+    const int b = blockIdx.x / p.NS, split = blockIdx.x - b * p.NS;
+    const int c = threadIdx.x % p.CC, pl = threadIdx.x / p.CC;
+    float mu[N], rs[N], ga[N], be[N], a0[N], a1[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        const int ch = c * N + e, g = ch / p.Cg;
+        mu[e] = p.mean[b * p.G + g]; rs[e] = p.rstd[b * p.G + g]; ga[e] = p.gamma[ch]; be[e] = p.beta[ch];
+        a0[e] = 0.f; a1[e] = 0.f;
+    }
+    const int p0 = split * p.pps, p1 = min(p.HW, p0 + p.pps);
+    const T* xb = reinterpret_cast<const T*>(p.x) + (int64_t)b * p.HW * p.ldx + c * N;
+    const T* gb = reinterpret_cast<const T*>(p.dy) + (int64_t)b * p.HW * p.lddy + c * N;
+    for (int px = p0 + pl; px < p1; px += p.PP) {
+        float v[N], d[N];
+        Vec<T>::ld(xb + (int64_t)px * p.ldx, v);
+        Vec<T>::ld(gb + (int64_t)px * p.lddy, d);
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            const float h = (v[e] - mu[e]) * rs[e];
+            float dz = d[e];
+            if (p.silu) dz *= silu_grad(h * ga[e] + be[e]);
+            a0[e] += dz * h; a1[e] += dz;
         }
     }
+    float* row = sm + (int64_t)pl * p.C * 2;
+#pragma unroll
+    for (int e = 0; e < N; ++e) { row[(c * N + e) * 2] = a0[e]; row[(c * N + e) * 2 + 1] = a1[e]; }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < p.C; ch += blockDim.x) {
+        float t0 = 0.f, t1 = 0.f;
+        for (int l = 0; l < p.PP; ++l) { t0 += sm[((int64_t)l * p.C + ch) * 2]; t1 += sm[((int64_t)l * p.C + ch) * 2 + 1]; }
+        float* o = p.ws + ((int64_t)blockIdx.x * p.C + ch) * 2;
+        o[0] = t0; o[1] = t1;
+    }
 }
 
-// NOTE (aliasing): when dx aliases dy and the slab is NOT in LDS, pass C would read dy after pass B
-// overwrote it; the launcher forbids aliasing in that case.
+// ---------------------------------------------------------------- backward: dx
+template <typename T>
+__global__ void gn_bwd_apply_kernel(const GnP p) {
+    constexpr int N = Vec<T>::N;
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // [C][2] per-sample channel sums, then [G][2]
+    float* gs = sm + (int64_t)p.C * 2;
+    const int b = blockIdx.x / p.NS, split = blockIdx.x - b * p.NS;
+    for (int ch = threadIdx.x; ch < p.C; ch += blockDim.x) {
+        float t0 = 0.f, t1 = 0.f;
+        for (int s2 = 0; s2 < p.NS; ++s2) {
+            const float* o = p.ws + ((int64_t)(b * p.NS + s2) * p.C + ch) * 2;
+            t0 += o[0]; t1 += o[1];
+        }
+        sm[ch * 2] = t0 * p.gamma[ch]; sm[ch * 2 + 1] = t1 * p.gamma[ch];      // gamma-weighted: sum(dxhat*xhat), sum(dxhat)
+    }
+    __syncthreads();
+    if (threadIdx.x < p.G) {
+        const int g = threadIdx.x;
+        float s2v = 0.f, s1v = 0.f;
+        for (int ch = g * p.Cg; ch < (g + 1) * p.Cg; ++ch) { s2v += sm[ch * 2]; s1v += sm[ch * 2 + 1]; }
+        const float inv_n = 1.0f / ((float)p.HW * (float)p.Cg);
+        gs[g * 2] = s1v * inv_n; gs[g * 2 + 1] = s2v * inv_n;
+    }
+    __syncthreads();
+    const int c = threadIdx.x % p.CC, pl = threadIdx.x / p.CC;
+    float mu[N], rs[N], ga[N], be[N], s1[N], s2[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        const int ch = c * N + e, g = ch / p.Cg;
+        mu[e] = p.mean[b * p.G + g]; rs[e] = p.rstd[b * p.G + g]; ga[e] = p.gamma[ch]; be[e] = p.beta[ch];
+        s1[e] = gs[g * 2]; s2[e] = gs[g * 2 + 1];
+    }
+    const int p0 = split * p.pps, p1 = min(p.HW, p0 + p.pps);
+    const T* xb = reinterpret_cast<const T*>(p.x) + (int64_t)b * p.HW * p.ldx + c * N;
+    const T* gb = reinterpret_cast<const T*>(p.dy) + (int64_t)b * p.HW * p.lddy + c * N;
+    T* ob = reinterpret_cast<T*>(p.dx) + (int64_t)b * p.HW * p.lddx + c * N;
+    for (int px = p0 + pl; px < p1; px += p.PP) {
+        float v[N], d[N];
+        Vec<T>::ld(xb + (int64_t)px * p.ldx, v);
+        Vec<T>::ld(gb + (int64_t)px * p.lddy, d);
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            const float h = (v[e] - mu[e]) * rs[e];
+            float dz = d[e];
+            if (p.silu) dz *= silu_grad(h * ga[e] + be[e]);
+            v[e] = rs[e] * (dz * ga[e] - s1[e] - h * s2[e]);
+        }
+        Vec<T>::st(ob + (int64_t)px * p.lddx, v);
+    }
+}
 
-// dgamma/dbeta[c] (+)= sum_b ws[{0,1}][b][c]: 64 columns x 4 batch lanes per block, fixed order
+// dgamma/dbeta[c] (+)= sum over rows (b, split) of ws[row][c][{0,1}]: 64 columns x 4 row lanes, fixed order
 __global__ __launch_bounds__(256) void gn_param_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, int B, int C, int accumulate) {
+                                                              float* __restrict__ dbeta, int rows, int C, int accumulate) {
     __shared__ float red[2][4][64];
     const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int c = blockIdx.x * 64 + cl;
     float ag = 0.f, ab = 0.f;
     if (c < C)
-        for (int b = rl; b < B; b += 4) { ag += ws[(int64_t)b * C + c]; ab += ws[(int64_t)B * C + (int64_t)b * C + c]; }
+        for (int r = rl; r < rows; r += 4) { ag += ws[((int64_t)r * C + c) * 2]; ab += ws[((int64_t)r * C + c) * 2 + 1]; }
     red[0][rl][cl] = ag; red[1][rl][cl] = ab;
     __syncthreads();
     if (rl == 0 && c < C) {
@@ -196,75 +233,91 @@ __global__ __launch_bounds__(256) void gn_param_reduce_kernel(const float* __res
     }
 }
 
+static int gn_plan(GnP& p, int dtype) {
+    const int N = dtype == PSG_BF16 ? 8 : 4;
+    PSG_REQUIRE(p.B > 0 && p.HW > 0 && p.C > 0 && p.G > 0 && p.C % p.G == 0, PSG_ERR_SHAPE, "groupnorm: B=%d HW=%d C=%d G=%d", p.B, p.HW, p.C, p.G);
+    PSG_REQUIRE(p.C % N == 0, PSG_ERR_SHAPE, "groupnorm: C=%d must be a multiple of %d", p.C, N);
+    PSG_REQUIRE(p.G <= 64, PSG_ERR_SHAPE, "groupnorm: G=%d > 64", p.G);
+    p.Cg = p.C / p.G;
+    p.CC = p.C / N;
+    PSG_REQUIRE(p.CC <= 1024, PSG_ERR_SHAPE, "groupnorm: C=%d too wide", p.C);
+    p.PP = 256 / p.CC;
+    if (p.PP < 1) p.PP = 1;
+    if (p.PP * p.CC < 64) p.PP = (64 + p.CC - 1) / p.CC;
+    int ns = (1024 + p.B - 1) / p.B;                       // ~4 workgroups per CU
+    const int maxns = (p.HW + 2 * p.PP - 1) / (2 * p.PP);  // at least 2 pixels per lane
+    if (ns > maxns) ns = maxns;
+    if (ns > GN_MAXSPLIT) ns = GN_MAXSPLIT;
+    if (ns < 1) ns = 1;
+    p.pps = (p.HW + ns - 1) / ns;
+    p.NS = (p.HW + p.pps - 1) / p.pps;
+    return PSG_OK;
+}
+
 }  // namespace psg
 using namespace psg;
 
 extern "C" {
 
-int psg_gn_init_attrs(void) {
-    const int big = 2 * GN_LDS_ELEMS * 4 + 64;
-#define SET_LDS(K) PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, big))
-    SET_LDS(gn_fwd_kernel<float>); SET_LDS(gn_fwd_kernel<bf16_t>);
-    SET_LDS(gn_bwd_kernel<float>); SET_LDS(gn_bwd_kernel<bf16_t>);
-#undef SET_LDS
-    return PSG_OK;
-}
+int psg_gn_init_attrs(void) { return PSG_OK; }
 
-static int gn_check(int B, int HW, int C, int G, int64_t lda, int64_t ldb) {
-    PSG_REQUIRE(B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0, PSG_ERR_SHAPE, "groupnorm: B=%d HW=%d C=%d G=%d", B, HW, C, G);
-    PSG_REQUIRE(((C / G) & 1) == 0, PSG_ERR_SHAPE, "groupnorm: channels per group (%d) must be even", C / G);
-    PSG_REQUIRE(C / G <= GN_THREADS, PSG_ERR_SHAPE, "groupnorm: channels per group (%d) > %d", C / G, GN_THREADS);
-    PSG_REQUIRE(lda >= C && ldb >= C && (lda & 1) == 0 && (ldb & 1) == 0, PSG_ERR_SHAPE, "groupnorm: row strides must be even and >= C");
-    PSG_REQUIRE((int64_t)HW * (C / G) < (1 << 24), PSG_ERR_SHAPE, "groupnorm: slab too large");
-    return PSG_OK;
-}
+int64_t psg_groupnorm_fwd_workspace_bytes(int B, int G) { return (int64_t)B * GN_MAXSPLIT * G * 2 * sizeof(float); }
+int64_t psg_groupnorm_bwd_workspace_bytes(int B, int C) { return (int64_t)B * GN_MAXSPLIT * C * 2 * sizeof(float); }
 
 int psg_groupnorm_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, const float* gamma, const float* beta,
-                      float* mean, float* rstd, int B, int HW, int C, int G, float eps, int silu, int dtype,
+                      float* mean, float* rstd, int B, int HW, int C, int G, float eps, int silu, int dtype, void* ws,
                       psg_stream_t stream) {
-    PSG_REQUIRE(x && y && gamma && beta && mean && rstd, PSG_ERR_ARG, "groupnorm_fwd: null pointer");
-    int rc = gn_check(B, HW, C, G, ldx, ldy);
+    PSG_REQUIRE(x && y && gamma && beta && mean && rstd && ws, PSG_ERR_ARG, "groupnorm_fwd: null pointer");
+    PSG_REQUIRE(dtype == PSG_F32 || dtype == PSG_BF16, PSG_ERR_DTYPE, "groupnorm_fwd: dtype %d", dtype);
+    GnP p = {};
+    p.x = x; p.y = y; p.gamma = gamma; p.beta = beta; p.mean = mean; p.rstd = rstd; p.ws = (float*)ws;
+    p.ldx = ldx; p.ldy = ldy; p.B = B; p.HW = HW; p.C = C; p.G = G; p.eps = eps; p.silu = silu;
+    int rc = gn_plan(p, dtype);
     if (rc) return rc;
-    const int nel = HW * (C / G);
-    const size_t esz = dtype == PSG_BF16 ? 2 : 4;
-    const size_t lds = nel <= GN_LDS_ELEMS ? (size_t)nel * esz : 0;
-    ProfScope prof(PROF_GN, 2.0 * (double)B * HW * C * (double)esz, (hipStream_t)stream);
-    if (dtype == PSG_F32)
-        hipLaunchKernelGGL(gn_fwd_kernel<float>, dim3(B * G), dim3(GN_THREADS), lds, (hipStream_t)stream, (const float*)x, ldx,
-                           (float*)y, ldy, gamma, beta, mean, rstd, HW, C, G, eps, silu);
-    else if (dtype == PSG_BF16)
-        hipLaunchKernelGGL(gn_fwd_kernel<bf16_t>, dim3(B * G), dim3(GN_THREADS), lds, (hipStream_t)stream, (const bf16_t*)x, ldx,
-                           (bf16_t*)y, ldy, gamma, beta, mean, rstd, HW, C, G, eps, silu);
-    else return set_error(PSG_ERR_DTYPE, "groupnorm_fwd: dtype %d", dtype);
+    const int N = dtype == PSG_BF16 ? 8 : 4;
+    PSG_REQUIRE(ldx >= C && ldy >= C && ldx % N == 0 && ldy % N == 0 && aligned16(x) && aligned16(y), PSG_ERR_ALIGN,
+                "groupnorm_fwd: rows must be 16-byte aligned (ld multiple of %d)", N);
+    hipStream_t s = (hipStream_t)stream;
+    const int threads = p.CC * p.PP, grid = B * p.NS;
+    const size_t lds1 = (size_t)p.PP * C * 2 * sizeof(float), lds2 = (size_t)G * 2 * sizeof(float);
+    ProfScope prof(PROF_GN, 2.0 * (double)B * HW * C * (double)(dtype == PSG_BF16 ? 2 : 4), s);
+    if (dtype == PSG_F32) {
+        hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(grid), dim3(threads), lds1, s, p);
+        hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(grid), dim3(threads), lds2, s, p);
+    } else {
+        hipLaunchKernelGGL(gn_stats_kernel<bf16_t>, dim3(grid), dim3(threads), lds1, s, p);
+        hipLaunchKernelGGL(gn_apply_kernel<bf16_t>, dim3(grid), dim3(threads), lds2, s, p);
+    }
     PSG_LAUNCH_CHECK("groupnorm_fwd");
     return PSG_OK;
 }
-
-int64_t psg_groupnorm_bwd_workspace_bytes(int B, int C) { return (int64_t)2 * B * C * sizeof(float); }
 
 int psg_groupnorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* gamma, const float* beta,
                       const float* mean, const float* rstd, void* dx, int64_t lddx, float* dgamma, float* dbeta, int B,
                       int HW, int C, int G, int silu, int accumulate, int dtype, void* ws, psg_stream_t stream) {
     PSG_REQUIRE(dy && x && gamma && beta && mean && rstd && dx && dgamma && dbeta && ws, PSG_ERR_ARG, "groupnorm_bwd: null pointer");
-    int rc = gn_check(B, HW, C, G, ldx, lddy);
+    PSG_REQUIRE(dtype == PSG_F32 || dtype == PSG_BF16, PSG_ERR_DTYPE, "groupnorm_bwd: dtype %d", dtype);
+    GnP p = {};
+    p.x = x; p.dy = dy; p.dx = dx; p.gamma = gamma; p.beta = beta; p.mean = const_cast<float*>(mean); p.rstd = const_cast<float*>(rstd);
+    p.ws = (float*)ws; p.ldx = ldx; p.lddy = lddy; p.lddx = lddx; p.B = B; p.HW = HW; p.C = C; p.G = G; p.silu = silu;
+    int rc = gn_plan(p, dtype);
     if (rc) return rc;
-    PSG_REQUIRE(lddx >= C && (lddx & 1) == 0, PSG_ERR_SHAPE, "groupnorm_bwd: lddx");
-    const int nel = HW * (C / G);
-    const size_t esz = dtype == PSG_BF16 ? 2 : 4;
-    const bool in_lds = nel <= GN_LDS_ELEMS;
-    PSG_REQUIRE(in_lds || dx != dy, PSG_ERR_ARG, "groupnorm_bwd: dx may alias dy only when the slab fits LDS");
-    const size_t lds = in_lds ? (size_t)(((nel + 7) & ~7) + nel) * esz : 0;
-    ProfScope prof(PROF_GN, 3.0 * (double)B * HW * C * (double)esz, (hipStream_t)stream);
-    if (dtype == PSG_F32)
-        hipLaunchKernelGGL(gn_bwd_kernel<float>, dim3(B * G), dim3(GN_THREADS), lds, (hipStream_t)stream, (const float*)dy, lddy,
-                           (const float*)x, ldx, gamma, beta, mean, rstd, (float*)dx, lddx, (float*)ws, B, HW, C, G, silu);
-    else if (dtype == PSG_BF16)
-        hipLaunchKernelGGL(gn_bwd_kernel<bf16_t>, dim3(B * G), dim3(GN_THREADS), lds, (hipStream_t)stream, (const bf16_t*)dy, lddy,
-                           (const bf16_t*)x, ldx, gamma, beta, mean, rstd, (bf16_t*)dx, lddx, (float*)ws, B, HW, C, G, silu);
-    else return set_error(PSG_ERR_DTYPE, "groupnorm_bwd: dtype %d", dtype);
+    const int N = dtype == PSG_BF16 ? 8 : 4;
+    PSG_REQUIRE(ldx >= C && lddy >= C && lddx >= C && ldx % N == 0 && lddy % N == 0 && lddx % N == 0 && aligned16(x) && aligned16(dy) &&
+                aligned16(dx), PSG_ERR_ALIGN, "groupnorm_bwd: rows must be 16-byte aligned (ld multiple of %d)", N);
+    hipStream_t s = (hipStream_t)stream;
+    const int threads = p.CC * p.PP, grid = B * p.NS;
+    const size_t lds1 = (size_t)p.PP * C * 2 * sizeof(float), lds2 = ((size_t)C + G) * 2 * sizeof(float);
+    ProfScope prof(PROF_GN, 3.0 * (double)B * HW * C * (double)(dtype == PSG_BF16 ? 2 : 4), s);
+    if (dtype == PSG_F32) {
+        hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, dim3(grid), dim3(threads), lds1, s, p);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(grid), dim3(threads), lds2, s, p);
+    } else {
+        hipLaunchKernelGGL(gn_bwd_reduce_kernel<bf16_t>, dim3(grid), dim3(threads), lds1, s, p);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(threads), lds2, s, p);
+    }
     PSG_LAUNCH_CHECK("groupnorm_bwd");
-    hipLaunchKernelGGL(gn_param_reduce_kernel, dim3((C + 63) / 64), dim3(256), 0, (hipStream_t)stream, (const float*)ws, dgamma,
-                       dbeta, B, C, accumulate);
+    hipLaunchKernelGGL(gn_param_reduce_kernel, dim3((C + 63) / 64), dim3(256), 0, s, (const float*)ws, dgamma, dbeta, B * p.NS, C, accumulate);
     PSG_LAUNCH_CHECK("groupnorm_param_reduce");
     return PSG_OK;
 }

@@ -348,8 +348,9 @@ class _GroupNormFn(torch.autograd.Function):
         HW = x.numel() // (B * Cc)
         y = torch.empty(x.shape, dtype=dtype, device=x.device)
         stats = torch.empty((2, B * groups), dtype=torch.float32, device=x.device)
+        ws = _lib.workspace(lib.psg_groupnorm_fwd_workspace_bytes(B, groups), x.device)
         check(lib.psg_groupnorm_fwd(ptr(xr), ldx, ptr(y), Cc, ptr(gamma), ptr(beta), ptr(stats[0]), ptr(stats[1]), B, HW, Cc, groups,
-                                    float(eps), int(silu), dtype_code(dtype), stream_ptr()), "psg_groupnorm_fwd")
+                                    float(eps), int(silu), dtype_code(dtype), ptr(ws), stream_ptr()), "psg_groupnorm_fwd")
         ctx.save_for_backward(xr, gamma, beta, stats)
         ctx.gamma_param, ctx.beta_param = gamma, beta
         ctx.meta = (B, HW, Cc, groups, silu, ldx, tuple(x.shape))

@@ -77,7 +77,7 @@ def test_argument_validation_without_gpu(lib):
     assert lib.psg_conv_fwd(C.byref(d), None) == -1
     w = WgradDesc()
     assert lib.psg_conv_wgrad_workspace_bytes(C.byref(w)) == -1
-    assert lib.psg_groupnorm_fwd(None, 0, None, 0, None, None, None, None, 1, 1, 32, 32, 1e-5, 0, 0, None) == -6
+    assert lib.psg_groupnorm_fwd(None, 0, None, 0, None, None, None, None, 1, 1, 32, 32, 1e-5, 0, 0, None, None) == -6
     assert lib.psg_kpad(72, 1) == 128 and lib.psg_kpad(72, 0) == 96 and lib.psg_kpad(2880, 1) == 2880
     assert lib.psg_attn_fwd(0x10, 8, 0x10, 8, 0x10, 8, 0x10, 8, 0x10, 1, 1, 4, 4, 6, 1.0, 0.0, 0, 0, None) == -1   # d % 4
 
