@@ -9,7 +9,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpsg_hip.so")
+LIB_PATH = os.environ.get("PSG_LIB_PATH") or os.path.join(_HERE, "libpsg_hip.so")   # override: A/B kernel builds in one GPU session
 
 PSG_F32, PSG_BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2

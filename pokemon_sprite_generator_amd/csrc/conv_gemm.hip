@@ -60,6 +60,7 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {   // byte offset in
 // MODE 2: generic (stride-2 data gradient, Cin = 8 first/last convs): per-thread tap decode
 template <typename T, int BM, int BN, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
+#if defined(__HIP_DEVICE_COMPILE__)      // the LDS-DMA builtin exists only in the device pass
     constexpr int CH = Elem<T>::CH;
     constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA tiles per wave along m / n
     constexpr int JX = BM / 32, JW = BN / 32;   // staging passes (32 rows per pass)
@@ -86,8 +87,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
     const int m0 = mt * BM, n0 = nt * BN;
 
     // ---- per-thread staging coordinates ------------------------------------
-    const int sc = tid & 7;          // chunk column within the K step
-    const int sr = tid >> 3;         // row within a 32-row pass
+    // Tiles go global -> LDS by LDS-DMA (buffer_load ... lds): the destination of a wave-instruction is
+    // wave-uniform base + lane*16, i.e. 8 consecutive 128-byte rows, so the XOR swizzle is applied on the SOURCE
+    // side: the lane sitting at physical chunk (tid & 7) of row sr fetches logical chunk sc.
+    const int sr = tid >> 3;                          // row within a 32-row pass
+    const int sc = (tid & 7) ^ ((sr >> 1) & 7);       // logical chunk this lane fetches ((row>>1)&7 is pass-invariant)
 
     // Branch-free gathers: raw buffer loads return 0 for an out-of-range offset, so padding taps,
     // rows beyond M / N and the K tail cost no control flow (and no per-load s_waitcnt).
@@ -120,11 +124,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
 
     // uniform tap state of the NEXT K step to load (fast modes): chunk offset inside the tap, kh, kw
     int t_c0 = 0, t_kh = 0, t_kw = 0;
-    u32x4 gw[JW], gx[JX];
-    auto load_tiles = [&](int kt) {
+    // wave-uniform LDS byte offset of this wave's 1 KiB slot in pass 0 (rows 8*wave .. 8*wave+7)
+    const int lds_wave = __builtin_amdgcn_readfirstlane(wave) * 1024;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    auto load_tiles = [&](int kt, int buf) {          // issue the LDS-DMA of K step kt into LDS buffer buf
         const uint32_t kbytes = (uint32_t)kt * 128u;          // 8 chunks of 16 B per K step
+        char* wdst = smem + buf * BUF_BYTES + lds_wave;
+        char* xdst = wdst + BN * 128;
 #pragma unroll
-        for (int j = 0; j < JW; ++j) gw[j] = __builtin_amdgcn_raw_buffer_load_b128(wrs, w_off[j] + kbytes, 0, 0);
+        for (int j = 0; j < JW; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(wdst + j * 4096), 16, w_off[j] + kbytes, 0, 0, 0);
         if (MODE != 2) {
             const int sgn = MODE == 0 ? 1 : -1;
             const int delta = (sgn * (t_kh * p.Wi + t_kw) * (int)p.ldx + t_c0 * CH) * ESZ;      // wave-uniform
@@ -134,7 +143,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
                 const bool ok = (unsigned)sh < (unsigned)p.Hi && (unsigned)sw < (unsigned)p.Wi;
                 uint32_t off = (uint32_t)(x_base[j] + delta);
                 off = ok ? off : OOB;
-                gx[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(xdst + j * 4096), 16, off, 0, 0, 0);
             }
             t_c0 += 8;
             if (t_c0 >= p.cpt) { t_c0 = 0; if (++t_kw == p.ks) { t_kw = 0; ++t_kh; } }
@@ -157,21 +166,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
                 }
                 uint32_t off = (uint32_t)(((x_base[j] + sh * p.Wi + sw) * (int)p.ldx + cc * CH) * ESZ);
                 off = ok ? off : OOB;
-                gx[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, off, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(xdst + j * 4096), 16, off, 0, 0, 0);
             }
         }
-    };
-    int st_w[JW], st_x[JX];          // LDS byte offsets of this thread's staging slots (loop-invariant)
-#pragma unroll
-    for (int j = 0; j < JW; ++j) st_w[j] = lds_off(sr + 32 * j, sc);
-#pragma unroll
-    for (int j = 0; j < JX; ++j) st_x[j] = BN * 128 + lds_off(sr + 32 * j, sc);
-    auto store_tiles = [&](int buf) {
-        char* base = smem + buf * BUF_BYTES;
-#pragma unroll
-        for (int j = 0; j < JW; ++j) *reinterpret_cast<u32x4*>(base + st_w[j]) = gw[j];
-#pragma unroll
-        for (int j = 0; j < JX; ++j) *reinterpret_cast<u32x4*>(base + st_x[j]) = gx[j];
     };
 
     f32x16 acc[TN][TM];
@@ -190,13 +187,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
 #pragma unroll
     for (int j = 0; j < TM; ++j) { const int row = wm * (TM * 32) + j * 32 + fr; rd_x[j] = BN * 128 + row * 128; sw_x[j] = (row >> 1) & 7; }
 
-    load_tiles(0);
-    store_tiles(0);
-    __syncthreads();
-
-    for (int kt = 0; kt < p.KT; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < p.KT) load_tiles(kt + 1);          // in flight during the MFMA phase
+    auto compute = [&](int buf) {
         const char* tb = smem + buf * BUF_BYTES;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -211,8 +202,18 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
 #pragma unroll
                 for (int j = 0; j < TM; ++j) acc[i][j] = Mma<T>::run(wf[i], xf[j], acc[i][j]);
         }
-        if (kt + 1 < p.KT) store_tiles(buf ^ 1);
-        __syncthreads();
+    };
+
+    const int KT = p.KT;
+    load_tiles(0, 0);
+    __syncthreads();                       // (drains vmcnt: the DMA of tile 0 has landed for every wave)
+
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        // buffer buf^1 was last read in step kt-1, which every wave finished before the barrier below
+        if (kt + 1 < KT) load_tiles(kt + 1, buf ^ 1);
+        compute(buf);
+        __syncthreads();                   // vmcnt(0) + barrier: tile kt+1 is in LDS, tile kt no longer needed
     }
 
     // ---- fused epilogue ------------------------------------------------------
@@ -256,6 +257,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
             }
         }
     }
+#endif
 }
 
 template <typename T, int BM, int BN>

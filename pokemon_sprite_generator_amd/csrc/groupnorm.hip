@@ -16,7 +16,15 @@
 
 namespace psg {
 
-constexpr int GN_MAXSPLIT = 8;
+constexpr int GN_MAXSPLIT = 16;
+#ifndef GN_U_VALUE
+#define GN_U_VALUE 4
+#endif
+#ifndef GN_UB_VALUE
+#define GN_UB_VALUE 2
+#endif
+constexpr int GN_U = GN_U_VALUE;     // loads in flight per lane, forward passes
+constexpr int GN_UB = GN_UB_VALUE;   // backward passes (two operands each)
 
 struct GnP {
     const void *x, *dy; void *y, *dx;
@@ -59,11 +67,19 @@ __global__ void gn_stats_kernel(const GnP p) {
     float s[N], q[N];
 #pragma unroll
     for (int e = 0; e < N; ++e) { s[e] = 0.f; q[e] = 0.f; }
-    for (int px = p0 + pl; px < p1; px += p.PP) {
-        float v[N];
-        Vec<T>::ld(xb + (int64_t)px * p.ldx, v);
+    for (int px = p0 + pl; px < p1; px += GN_U * p.PP) {      // GN_U independent 16-byte loads in flight per lane
+        float v[GN_U][N];
 #pragma unroll
-        for (int e = 0; e < N; ++e) { s[e] += v[e]; q[e] += v[e] * v[e]; }
+        for (int u = 0; u < GN_U; ++u) {
+            const int pu = px + u * p.PP;
+            Vec<T>::ld(xb + (int64_t)(pu < p1 ? pu : px) * p.ldx, v[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < GN_U; ++u) {
+            const float w = (px + u * p.PP) < p1 ? 1.f : 0.f;
+#pragma unroll
+            for (int e = 0; e < N; ++e) { s[e] += w * v[u][e]; q[e] += w * v[u][e] * v[u][e]; }
+        }
     }
     float* row = sm + (int64_t)pl * p.C * 2;
 #pragma unroll
@@ -112,12 +128,20 @@ __global__ void gn_apply_kernel(const GnP p) {
     const int p0 = split * p.pps, p1 = min(p.HW, p0 + p.pps);
     const T* xb = reinterpret_cast<const T*>(p.x) + (int64_t)b * p.HW * p.ldx + c * N;
     T* yb = reinterpret_cast<T*>(p.y) + (int64_t)b * p.HW * p.ldy + c * N;
-    for (int px = p0 + pl; px < p1; px += p.PP) {
-        float v[N];
-        Vec<T>::ld(xb + (int64_t)px * p.ldx, v);
+    for (int px = p0 + pl; px < p1; px += GN_U * p.PP) {
+        float v[GN_U][N];
 #pragma unroll
-        for (int e = 0; e < N; ++e) { v[e] = v[e] * sc[e] + sh[e]; if (p.silu) v[e] = silu_f(v[e]); }
-        Vec<T>::st(yb + (int64_t)px * p.ldy, v);
+        for (int u = 0; u < GN_U; ++u) {
+            const int pu = px + u * p.PP;
+            Vec<T>::ld(xb + (int64_t)(pu < p1 ? pu : px) * p.ldx, v[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < GN_U; ++u) {
+            const int pu = px + u * p.PP;
+#pragma unroll
+            for (int e = 0; e < N; ++e) { v[u][e] = v[u][e] * sc[e] + sh[e]; if (p.silu) v[u][e] = silu_f(v[u][e]); }
+            if (pu < p1) Vec<T>::st(yb + (int64_t)pu * p.ldy, v[u]);
+        }
     }
 }
 
@@ -138,16 +162,24 @@ __global__ void gn_bwd_reduce_kernel(const GnP p) {
     const int p0 = split * p.pps, p1 = min(p.HW, p0 + p.pps);
     const T* xb = reinterpret_cast<const T*>(p.x) + (int64_t)b * p.HW * p.ldx + c * N;
     const T* gb = reinterpret_cast<const T*>(p.dy) + (int64_t)b * p.HW * p.lddy + c * N;
-    for (int px = p0 + pl; px < p1; px += p.PP) {
-        float v[N], d[N];
-        Vec<T>::ld(xb + (int64_t)px * p.ldx, v);
-        Vec<T>::ld(gb + (int64_t)px * p.lddy, d);
+    for (int px = p0 + pl; px < p1; px += GN_UB * p.PP) {
+        float v[GN_UB][N], d[GN_UB][N];
 #pragma unroll
-        for (int e = 0; e < N; ++e) {
-            const float h = (v[e] - mu[e]) * rs[e];
-            float dz = d[e];
-            if (p.silu) dz *= silu_grad(h * ga[e] + be[e]);
-            a0[e] += dz * h; a1[e] += dz;
+        for (int u = 0; u < GN_UB; ++u) {
+            const int pu = px + u * p.PP, ps = pu < p1 ? pu : px;
+            Vec<T>::ld(xb + (int64_t)ps * p.ldx, v[u]);
+            Vec<T>::ld(gb + (int64_t)ps * p.lddy, d[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < GN_UB; ++u) {
+            const float w = (px + u * p.PP) < p1 ? 1.f : 0.f;
+#pragma unroll
+            for (int e = 0; e < N; ++e) {
+                const float h = (v[u][e] - mu[e]) * rs[e];
+                float dz = d[u][e] * w;
+                if (p.silu) dz *= silu_grad(h * ga[e] + be[e]);
+                a0[e] += dz * h; a1[e] += dz;
+            }
         }
     }
     float* row = sm + (int64_t)pl * p.C * 2;
@@ -176,6 +208,10 @@ __global__ void gn_bwd_apply_kernel(const GnP p) {
             t0 += o[0]; t1 += o[1];
         }
         sm[ch * 2] = t0 * p.gamma[ch]; sm[ch * 2 + 1] = t1 * p.gamma[ch];      // gamma-weighted: sum(dxhat*xhat), sum(dxhat)
+        if (split == 0) {                                                      // per-sample sums for dgamma / dbeta
+            float* o2 = p.ws + ((int64_t)p.B * p.NS * p.C + (int64_t)b * p.C + ch) * 2;
+            o2[0] = t0; o2[1] = t1;
+        }
     }
     __syncthreads();
     if (threadIdx.x < p.G) {
@@ -198,38 +234,52 @@ __global__ void gn_bwd_apply_kernel(const GnP p) {
     const T* xb = reinterpret_cast<const T*>(p.x) + (int64_t)b * p.HW * p.ldx + c * N;
     const T* gb = reinterpret_cast<const T*>(p.dy) + (int64_t)b * p.HW * p.lddy + c * N;
     T* ob = reinterpret_cast<T*>(p.dx) + (int64_t)b * p.HW * p.lddx + c * N;
-    for (int px = p0 + pl; px < p1; px += p.PP) {
-        float v[N], d[N];
-        Vec<T>::ld(xb + (int64_t)px * p.ldx, v);
-        Vec<T>::ld(gb + (int64_t)px * p.lddy, d);
+    for (int px = p0 + pl; px < p1; px += GN_UB * p.PP) {
+        float v[GN_UB][N], d[GN_UB][N];
 #pragma unroll
-        for (int e = 0; e < N; ++e) {
-            const float h = (v[e] - mu[e]) * rs[e];
-            float dz = d[e];
-            if (p.silu) dz *= silu_grad(h * ga[e] + be[e]);
-            v[e] = rs[e] * (dz * ga[e] - s1[e] - h * s2[e]);
+        for (int u = 0; u < GN_UB; ++u) {
+            const int pu = px + u * p.PP, ps = pu < p1 ? pu : px;
+            Vec<T>::ld(xb + (int64_t)ps * p.ldx, v[u]);
+            Vec<T>::ld(gb + (int64_t)ps * p.lddy, d[u]);
         }
-        Vec<T>::st(ob + (int64_t)px * p.lddx, v);
+#pragma unroll
+        for (int u = 0; u < GN_UB; ++u) {
+            const int pu = px + u * p.PP;
+#pragma unroll
+            for (int e = 0; e < N; ++e) {
+                const float h = (v[u][e] - mu[e]) * rs[e];
+                float dz = d[u][e];
+                if (p.silu) dz *= silu_grad(h * ga[e] + be[e]);
+                v[u][e] = rs[e] * (dz * ga[e] - s1[e] - h * s2[e]);
+            }
+            if (pu < p1) Vec<T>::st(ob + (int64_t)pu * p.lddx, v[u]);
+        }
     }
 }
 
 // dgamma/dbeta[c] (+)= sum over rows (b, split) of ws[row][c][{0,1}]: 64 columns x 4 row lanes, fixed order
-__global__ __launch_bounds__(256) void gn_param_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dgamma,
-                                                              float* __restrict__ dbeta, int rows, int C, int accumulate) {
-    __shared__ float red[2][4][64];
-    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+__global__ __launch_bounds__(1024) void gn_param_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dgamma,
+                                                               float* __restrict__ dbeta, int rows, int C, int accumulate) {
+    __shared__ float red[2][16][32];               // 32 columns x 16 row lanes (x2 values): few rows per lane
+    const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;   // thread -> (column pair lane, row lane of 32)
+    const int c = blockIdx.x * 32 + cl;
     float ag = 0.f, ab = 0.f;
     if (c < C)
-        for (int r = rl; r < rows; r += 4) { ag += ws[((int64_t)r * C + c) * 2]; ab += ws[((int64_t)r * C + c) * 2 + 1]; }
-    red[0][rl][cl] = ag; red[1][rl][cl] = ab;
+        for (int r = rl; r < rows; r += 32) { const float2 v = *reinterpret_cast<const float2*>(ws + ((int64_t)r * C + c) * 2); ag += v.x; ab += v.y; }
+    // two-level fixed-order combine: 32 row lanes -> 16 -> 1
+    if (rl >= 16) { red[0][rl - 16][cl] = ag; red[1][rl - 16][cl] = ab; }
+    __syncthreads();
+    if (rl < 16) { ag += red[0][rl][cl]; ab += red[1][rl][cl]; }
+    __syncthreads();
+    if (rl < 16) { red[0][rl][cl] = ag; red[1][rl][cl] = ab; }
     __syncthreads();
     if (rl == 0 && c < C) {
-        ag = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
-        ab = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
-        if (accumulate) { ag += dgamma[c]; ab += dbeta[c]; }
-        dgamma[c] = ag;
-        dbeta[c] = ab;
+        float tg = 0.f, tb = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { tg += red[0][i][cl]; tb += red[1][i][cl]; }
+        if (accumulate) { tg += dgamma[c]; tb += dbeta[c]; }
+        dgamma[c] = tg;
+        dbeta[c] = tb;
     }
 }
 
@@ -244,8 +294,8 @@ static int gn_plan(GnP& p, int dtype) {
     p.PP = 256 / p.CC;
     if (p.PP < 1) p.PP = 1;
     if (p.PP * p.CC < 64) p.PP = (64 + p.CC - 1) / p.CC;
-    int ns = (1024 + p.B - 1) / p.B;                       // ~4 workgroups per CU
-    const int maxns = (p.HW + 2 * p.PP - 1) / (2 * p.PP);  // at least 2 pixels per lane
+    int ns = (2048 + p.B - 1) / p.B;                       // ~8 workgroups per CU
+    const int maxns = (p.HW + 4 * p.PP - 1) / (4 * p.PP);  // about 4 pixels per lane at least
     if (ns > maxns) ns = maxns;
     if (ns > GN_MAXSPLIT) ns = GN_MAXSPLIT;
     if (ns < 1) ns = 1;
@@ -262,7 +312,7 @@ extern "C" {
 int psg_gn_init_attrs(void) { return PSG_OK; }
 
 int64_t psg_groupnorm_fwd_workspace_bytes(int B, int G) { return (int64_t)B * GN_MAXSPLIT * G * 2 * sizeof(float); }
-int64_t psg_groupnorm_bwd_workspace_bytes(int B, int C) { return (int64_t)B * GN_MAXSPLIT * C * 2 * sizeof(float); }
+int64_t psg_groupnorm_bwd_workspace_bytes(int B, int C) { return (int64_t)B * (GN_MAXSPLIT + 1) * C * 2 * sizeof(float); }
 
 int psg_groupnorm_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, const float* gamma, const float* beta,
                       float* mean, float* rstd, int B, int HW, int C, int G, float eps, int silu, int dtype, void* ws,
@@ -317,7 +367,8 @@ int psg_groupnorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, 
         hipLaunchKernelGGL(gn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(threads), lds2, s, p);
     }
     PSG_LAUNCH_CHECK("groupnorm_bwd");
-    hipLaunchKernelGGL(gn_param_reduce_kernel, dim3((C + 63) / 64), dim3(256), 0, s, (const float*)ws, dgamma, dbeta, B * p.NS, C, accumulate);
+    hipLaunchKernelGGL(gn_param_reduce_kernel, dim3((C + 31) / 32), dim3(1024), 0, s, (const float*)ws + (int64_t)B * p.NS * C * 2, dgamma, dbeta,
+                       B, C, accumulate);
     PSG_LAUNCH_CHECK("groupnorm_param_reduce");
     return PSG_OK;
 }

@@ -28,11 +28,12 @@ struct WgP {
 };
 
 template <typename T> struct WgCfg;
-template <> struct WgCfg<bf16_t> { static constexpr int BKP = 64; static constexpr int ROWB = 320; };  // bytes per LDS row
+template <> struct WgCfg<bf16_t> { static constexpr int BKP = 64; static constexpr int ROWB = 256; };  // bytes per LDS row
 template <> struct WgCfg<float> { static constexpr int BKP = 32; static constexpr int ROWB = 512; };
 
 template <typename T>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
+#if defined(__HIP_DEVICE_COMPILE__)      // the LDS-DMA builtin exists only in the device pass
     constexpr int CH = Elem<T>::CH;
     constexpr int BKP = WgCfg<T>::BKP;
     constexpr int ROWB = WgCfg<T>::ROWB;
@@ -51,9 +52,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
     const int rt = bid % p.rtiles; const int qt = bid / p.rtiles;
     const int co0 = rt * 128, q0 = qt * 128;
 
-    const int sc = tid % CPR, sr = tid / CPR;
-    const T* xg = reinterpret_cast<const T*>(p.x);
-    const T* dyg = reinterpret_cast<const T*>(p.dy);
+    // Tiles go global -> LDS by LDS-DMA (wave-uniform base + lane*16: whole 256/512-byte rows, unpadded).  For bf16
+    // the transposed fragment reads (4 consecutive pixel rows x 64-byte column windows per half-wave) are made
+    // conflict-free by XOR-ing the 16-byte chunk index with (row & 3) << 2 - applied on the SOURCE side: the lane
+    // at physical chunk (tid % CPR) of row sr fetches logical chunk sc.  (row & 3 is the same in every pass.)
+    const int sr = tid / CPR;
+    const int sc = sizeof(T) == 2 ? ((tid % CPR) ^ ((sr & 3) << 2)) : (tid % CPR);
 
     // A operand (dY): column chunk -> co
     const int a_co = co0 + sc * CH;
@@ -92,8 +96,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
         r_pix[j] = b * SB + r_ho[j] * SH + r_wo[j] * SW;
         r_a[j] = (m * (int)p.lddy + a_co) * ESZ;
     }
-    u32x4 ga[NPASS], gb[NPASS];
-    auto load_tiles = [&]() {          // loads the rows at the current odometer state, then advances it
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const int lds_wave = __builtin_amdgcn_readfirstlane(wave) * 1024;      // this wave's 1 KiB slot inside a pass
+    constexpr int PASS_BYTES = RPP * ROWB;                                  // = 4096
+    auto load_tiles = [&](int buf) {   // DMA the rows at the current odometer state into LDS buffer buf, then advance
+        char* adst = smem + buf * 2 * TILE_BYTES + lds_wave;
+        char* bdst = adst + TILE_BYTES;
 #pragma unroll
         for (int j = 0; j < NPASS; ++j) {
             const bool m_ok = r_m[j] < p.M;
@@ -101,8 +109,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
             const int sh = r_ho[j] * p.stride - p.pad + b_kh, sw = r_wo[j] * p.stride - p.pad + b_kw;
             const bool ok = m_ok && b_ok && (unsigned)sh < (unsigned)p.Hi && (unsigned)sw < (unsigned)p.Wi;
             const uint32_t boff = ok ? (uint32_t)(r_pix[j] + b_const) : OOB;
-            ga[j] = __builtin_amdgcn_raw_buffer_load_b128(yrs, aoff, 0, 0);
-            gb[j] = __builtin_amdgcn_raw_buffer_load_b128(xrs, boff, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(yrs, (lds_ptr_t)(adst + j * PASS_BYTES), 16, aoff, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(bdst + j * PASS_BYTES), 16, boff, 0, 0, 0);
             // advance by BKP pixels
             r_m[j] += BKP; r_a[j] += a_step;
             int wo = r_wo[j] + od_dW;
@@ -115,15 +123,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
             r_pix[j] += od_A0 + (c1 ? od_K1 : 0) + (c2 ? od_K2 : 0);
         }
     };
-    auto store_tiles = [&](int buf) {
-        char* base = smem + buf * 2 * TILE_BYTES;
-#pragma unroll
-        for (int j = 0; j < NPASS; ++j) {
-            const int row = sr + RPP * j;
-            *reinterpret_cast<u32x4*>(base + row * ROWB + sc * 16) = ga[j];
-            *reinterpret_cast<u32x4*>(base + TILE_BYTES + row * ROWB + sc * 16) = gb[j];
-        }
-    };
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -133,15 +132,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    if (nsteps > 0) {
-        load_tiles();
-        store_tiles(0);
-    }
-    __syncthreads();
+    if (nsteps > 0) load_tiles(0);
+    __syncthreads();                       // drains vmcnt: tile 0 has landed
 
     for (int st = 0; st < nsteps; ++st) {
         const int buf = st & 1;
-        if (st + 1 < nsteps) load_tiles();
+        if (st + 1 < nsteps) load_tiles(buf ^ 1);      // buffer buf^1 was last read in step st-1 (barrier below)
         const char* ab = smem + buf * 2 * TILE_BYTES;
         const char* bb = ab + TILE_BYTES;
         if constexpr (sizeof(T) == 2) {
@@ -154,12 +150,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
                 bf16x8 af[2], bf[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    const int colA = wr * 64 + i * 32 + ccol;
-                    const int colB = wc * 64 + i * 32 + ccol;
-                    s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ab + (kk * 16 + krow) * ROWB + colA * 2));
-                    s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ab + (kk * 16 + krow + 4) * ROWB + colA * 2));
-                    s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(bb + (kk * 16 + krow) * ROWB + colB * 2));
-                    s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(bb + (kk * 16 + krow + 4) * ROWB + colB * 2));
+                    // column -> (16-byte chunk, offset inside it); the chunk is XOR-swizzled with (row & 3) << 2 == q4 << 2
+                    const int colA = wr * 64 + i * 32 + ccol, colB = wc * 64 + i * 32 + ccol;
+                    const int offA = ((((colA >> 3) ^ (q4 << 2)) << 4) + ((colA & 7) << 1));
+                    const int offB = ((((colB >> 3) ^ (q4 << 2)) << 4) + ((colB & 7) << 1));
+                    s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ab + (kk * 16 + krow) * ROWB + offA));
+                    s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ab + (kk * 16 + krow + 4) * ROWB + offA));
+                    s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(bb + (kk * 16 + krow) * ROWB + offB));
+                    s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(bb + (kk * 16 + krow + 4) * ROWB + offB));
                     typedef __attribute__((ext_vector_type(8))) short s16x8;
                     s16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
                     s16x8 bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
@@ -187,8 +185,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
                     for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
             }
         }
-        if (st + 1 < nsteps) store_tiles(buf ^ 1);
-        __syncthreads();
+        __syncthreads();                   // vmcnt(0) + barrier: next tile landed, this one no longer needed
     }
 
     // partial slab: ws[split][co][q]
@@ -207,6 +204,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
             }
         }
     }
+#endif
 }
 
 // dw[co][ci][tap] (+)= sum_s ws[s][co][tap*Cin + ci]; one block per (co, 256-ci chunk), LDS transpose
@@ -257,7 +255,7 @@ using namespace psg;
 extern "C" {
 
 int psg_wgrad_init_attrs(void) {
-    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 320));
+    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 256));
     PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32 * 512));
     return PSG_OK;
 }
@@ -306,7 +304,7 @@ int psg_conv_wgrad(const psg_wgrad_desc* d, psg_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     {
         ProfScope prof(PROF_WGRAD, 2.0 * (double)p.M * (double)p.Cout * (double)p.Q, s);
-        if (d->dtype == PSG_BF16) hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3(grid), dim3(256), 4 * 64 * 320, s, p);
+        if (d->dtype == PSG_BF16) hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3(grid), dim3(256), 4 * 64 * 256, s, p);
         else hipLaunchKernelGGL(wgrad_kernel<float>, dim3(grid), dim3(256), 4 * 32 * 512, s, p);
     }
     PSG_LAUNCH_CHECK("wgrad");
