@@ -1,0 +1,120 @@
+"""-m gpu: the data-parallel train step with 2 ranks (one process each, both on cuda:0, gloo transport so
+it runs on a 1-GPU box; the production backend is RCCL).  Exercises the real path: gradient sink ->
+bucket-ready callbacks -> async all-reduce on the side stream -> finish() -> clip -> AdamW, and checks that
+2 ranks x batch 2 reproduce a single process at batch 4 (loss mean and averaged gradients)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _make(seed=0):
+    import pokemon_sprite_generator_amd as psg
+    torch.manual_seed(seed)
+    # a real (small) slice of the network: one attention UNetBlock, wrapped so the stepper sees a UNet-like module
+    class Tiny(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.inp = torch.nn.Conv2d(8, 64, 3, padding=1)
+            self.blk = psg.UNetBlock(64, 64, 128, 256, has_attention=True, num_heads=4)
+            self.out = torch.nn.Conv2d(64, 8, 3, padding=1)
+            self.te = psg.TimestepEmbedding(128)
+            self.compute_dtype = torch.float32
+
+        def forward(self, x, t, text):
+            from pokemon_sprite_generator_amd import ops
+            dt = torch.float32
+            h = ops.conv2d(ops.nchw_to_nhwc(x, dt), self.inp.weight, self.inp.bias)
+            pooled, tx = ops.text_pool(text, dt)
+            h = self.blk.nhwc(h, self.te.embed(t, dt), pooled, tx)
+            return ops.nhwc_to_nchw(ops.conv2d(h, self.out.weight, self.out.bias))
+    return Tiny().cuda().eval()      # eval: dropout off so runs are comparable
+
+
+def _batch():
+    g = torch.Generator().manual_seed(7)
+    return (torch.randn(4, 8, 9, 9, generator=g), torch.randn(4, 32, 256, generator=g),
+            torch.tensor([10, 400, 700, 999]), torch.randn(4, 8, 9, 9, generator=g))
+
+
+def _step(model, lat, txt, t, nz, distributed, bucket_bytes=1 << 16):
+    import pokemon_sprite_generator_amd as psg
+    st = psg.DiffusionStepper(model, psg.NoiseScheduler(), lr=1e-3, weight_decay=0.0, max_grad_norm=1e9,
+                              distributed=distributed, bucket_bytes=bucket_bytes)
+    model_mode = model.training
+    out = st.train_step(lat.cuda(), txt.cuda(), t.cuda(), nz.cuda())
+    model.train(model_mode)
+    torch.cuda.synchronize()
+    return st, out
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        model = _make()
+        lat, txt, t, nz = _batch()
+        sl = slice(2 * rank, 2 * rank + 2)
+        # DiffusionStepper.train_step puts the model in train mode; keep dropout off by zeroing p via eval-time block
+        import pokemon_sprite_generator_amd.unet as U
+        U.ATTN_DROPOUT = 0.0
+        st, out = _step(model, lat[sl], txt[sl], t[sl], nz[sl], True)
+        assert st.reducer is not None and st.reducer.world == 2 and len(st.reducer.buckets) > 1
+        q.put((rank, float(out["loss"].item()), st.arena.flat.detach().cpu().numpy(), {k: v.detach().cpu().numpy() for k, v in model.state_dict().items()}))
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        q.put((rank, None, traceback.format_exc(), None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_step_matches_single_process():
+    import pokemon_sprite_generator_amd.unet as U
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[1] is not None, r[2]
+    res = [(r[0], r[1], torch.from_numpy(r[2]), {k: torch.from_numpy(v) for k, v in r[3].items()}) for r in res]
+    # single process, whole batch
+    old = U.ATTN_DROPOUT
+    U.ATTN_DROPOUT = 0.0
+    try:
+        model = _make()
+        lat, txt, t, nz = _batch()
+        st, out = _step(model, lat, txt, t, nz, False)
+    finally:
+        U.ATTN_DROPOUT = old
+    ref_flat = st.arena.flat.detach().cpu()
+    # both ranks hold the same averaged gradients == the global-batch gradients
+    assert torch.allclose(res[0][2], res[1][2], rtol=0, atol=0), "ranks disagree after all-reduce"
+    err = float((res[0][2] - ref_flat).abs().max() / ref_flat.abs().max())
+    assert err < 1e-4, f"averaged shard gradients vs global-batch gradients: {err}"
+    assert abs(0.5 * (res[0][1] + res[1][1]) - float(out["loss"].item())) < 1e-5
+    # identical parameter update on every rank and equal to the single-process update
+    sd = model.state_dict()
+    for k in sd:
+        assert torch.equal(res[0][3][k], res[1][3][k]), k
+        if sd[k].dtype.is_floating_point:
+            assert float((res[0][3][k] - sd[k].cpu()).abs().max()) < 1e-5, k
