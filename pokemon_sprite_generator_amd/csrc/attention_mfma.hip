@@ -51,12 +51,25 @@ __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >
 __device__ __forceinline__ void stage_tile(char* dst, const bf16_t* src, int64_t ld, int row0, int nrows, int nvalid_end,
                                            int d, int d32, int stride, int tid, int nthreads) {
     const int cpr = d32 >> 3;                      // 16-byte chunks per row
-    for (int e = tid; e < nrows * cpr; e += nthreads) {
-        const int r = e / cpr, c = e - r * cpr;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        const int gr = row0 + r;
-        if (gr < nvalid_end && c * 8 < d) v = *reinterpret_cast<const uint4*>(src + (int64_t)gr * ld + c * 8);
-        *reinterpret_cast<uint4*>(dst + r * stride + c * 16) = v;
+    const int n = nrows * cpr;
+    constexpr int U = 8;                           // independent 16-byte loads in flight per lane
+    for (int e0 = tid; e0 < n; e0 += nthreads * U) {
+        uint4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * nthreads;
+            const int r = e / cpr, c = e - r * cpr;
+            const int gr = row0 + r;
+            const bool ok = e < n && gr < nvalid_end && c * 8 < d;
+            const uint4 t = *reinterpret_cast<const uint4*>(src + (ok ? (int64_t)gr * ld + c * 8 : 0));   // unconditional load (no per-load branch + wait)
+            v[u] = ok ? t : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int e = e0 + u * nthreads;
+            const int r = e / cpr, c = e - r * cpr;
+            if (e < n) *reinterpret_cast<uint4*>(dst + r * stride + c * 16) = v[u];
+        }
     }
 }
 
@@ -103,8 +116,8 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const AttnMP p) {
         bf16x8 qf[ND];
 #pragma unroll
         for (int ks = 0; ks < ND; ++ks) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (lok) v = *reinterpret_cast<const uint4*>(qg + (int64_t)l * p.ldq + 16 * ks + 8 * fh);
+            uint4 v = *reinterpret_cast<const uint4*>(qg + (int64_t)(lok ? l : 0) * p.ldq + 16 * ks + 8 * fh);   // unconditional
+            if (!lok) v = make_uint4(0, 0, 0, 0);
             qf[ks] = *reinterpret_cast<bf16x8*>(&v);
         }
         f32x16 oacc[NDT];
@@ -207,11 +220,10 @@ __global__ __launch_bounds__(256) void attn_dq_mfma(const AttnMP p) {
         bf16x8 qf[ND], gf[ND];
 #pragma unroll
         for (int ks = 0; ks < ND; ++ks) {
-            uint4 v = make_uint4(0, 0, 0, 0), w = make_uint4(0, 0, 0, 0);
-            if (lok) {
-                v = *reinterpret_cast<const uint4*>(qg + (int64_t)l * p.ldq + 16 * ks + 8 * fh);
-                w = *reinterpret_cast<const uint4*>(gg + (int64_t)l * p.lddo + 16 * ks + 8 * fh);
-            }
+            const int ls = lok ? l : 0;
+            uint4 v = *reinterpret_cast<const uint4*>(qg + (int64_t)ls * p.ldq + 16 * ks + 8 * fh);    // unconditional loads
+            uint4 w = *reinterpret_cast<const uint4*>(gg + (int64_t)ls * p.lddo + 16 * ks + 8 * fh);
+            if (!lok) { v = make_uint4(0, 0, 0, 0); w = make_uint4(0, 0, 0, 0); }
             qf[ks] = *reinterpret_cast<bf16x8*>(&v);
             gf[ks] = *reinterpret_cast<bf16x8*>(&w);
         }

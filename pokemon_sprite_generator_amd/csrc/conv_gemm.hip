@@ -58,12 +58,19 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {   // byte offset in
 // MODE 0: forward gather, K step inside one tap (Cin % K-step == 0)   [every 3x3 / 1x1 layer of the U-Net body]
 // MODE 1: data-gradient gather of a stride-1 conv, same fast decode
 // MODE 2: generic (stride-2 data gradient, Cin = 8 first/last convs): per-thread tap decode
-template <typename T, int BM, int BN, int MODE>
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
+// NT threads (256: 4 waves as 2m x 2n; 512: 8 waves as 4m x 2n), NSTAGE LDS tile buffers:
+//   NSTAGE 2: the tile of step kt+1 is requested at the top of step kt (plain __syncthreads, drains vmcnt)
+//   NSTAGE 3: the tile of step kt+2 is requested at the top of step kt and stays in flight ACROSS the barrier
+//             (counted s_waitcnt vmcnt + raw s_barrier): two MFMA phases to hide the L2/HBM round trip
+template <typename T, int BM, int BN, int MODE, int NT, int NSTAGE>
+__global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(const ConvP p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // the LDS-DMA builtin exists only in the device pass
     constexpr int CH = Elem<T>::CH;
-    constexpr int TM = BM / 64, TN = BN / 64;   // 32x32 MFMA tiles per wave along m / n
-    constexpr int JX = BM / 32, JW = BN / 32;   // staging passes (32 rows per pass)
+    constexpr int WAVES_M = NT / 128;           // waves along m (2 along n)
+    constexpr int TM = BM / (32 * WAVES_M), TN = BN / 64;   // 32x32 MFMA tiles per wave along m / n
+    constexpr int RPP = NT / 8;                 // rows per staging pass (8 lanes x 16 B per 128-byte row)
+    constexpr int JX = BM / RPP, JW = BN / RPP; // staging passes
+    constexpr int PASS_BYTES = RPP * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // [buf][W tile BN rows | X tile BM rows], 128 B per row
     constexpr int BUF_BYTES = (BM + BN) * 128;
@@ -97,12 +104,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
     // rows beyond M / N and the K tail cost no control flow (and no per-load s_waitcnt).
     constexpr uint32_t OOB = 0x80000000u;          // extents are < 2 GiB (checked on the host)
     constexpr int ESZ = (int)sizeof(T);
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.w), 0, p.w_bytes, 0x00020000);
+    const u32x4 xrs = make_rsrc(p.x, p.x_bytes);
+    const u32x4 wrs = make_rsrc(p.w, p.w_bytes);
     uint32_t w_off[JW];              // byte offset of (row, chunk sc), or OOB
 #pragma unroll
     for (int j = 0; j < JW; ++j) {
-        const int n = n0 + sr + 32 * j;
+        const int n = n0 + sr + RPP * j;
         w_off[j] = n < p.N ? (uint32_t)(((int64_t)n * p.ldw + sc * CH) * ESZ) : OOB;
     }
     int x_hb[JX], x_wb[JX], x_base[JX];   // tap-0 source row / col, and byte offset of that pixel (+ chunk sc)
@@ -110,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
         const int HoWo = p.Ho * p.Wo;
 #pragma unroll
         for (int j = 0; j < JX; ++j) {
-            const int m = m0 + sr + 32 * j;
+            const int m = m0 + sr + RPP * j;
             if (m < p.M) {
                 const int b = m / HoWo, rm = m - b * HoWo;
                 const int ho = rm / p.Wo, wo = rm - ho * p.Wo;
@@ -125,15 +132,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
     // uniform tap state of the NEXT K step to load (fast modes): chunk offset inside the tap, kh, kw
     int t_c0 = 0, t_kh = 0, t_kw = 0;
     // wave-uniform LDS byte offset of this wave's 1 KiB slot in pass 0 (rows 8*wave .. 8*wave+7)
-    const int lds_wave = __builtin_amdgcn_readfirstlane(wave) * 1024;
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef __attribute__((address_space(3))) char* lds_ptr_t;
+    const uint32_t lds_wave = (uint32_t)(size_t)(lds_ptr_t)smem + (uint32_t)__builtin_amdgcn_readfirstlane(wave) * 1024u;
     auto load_tiles = [&](int kt, int buf) {          // issue the LDS-DMA of K step kt into LDS buffer buf
         const uint32_t kbytes = (uint32_t)kt * 128u;          // 8 chunks of 16 B per K step
-        char* wdst = smem + buf * BUF_BYTES + lds_wave;
-        char* xdst = wdst + BN * 128;
+        const uint32_t wdst = lds_wave + (uint32_t)buf * BUF_BYTES;
+        const uint32_t xdst = wdst + BN * 128;
 #pragma unroll
         for (int j = 0; j < JW; ++j)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(wrs, (lds_ptr_t)(wdst + j * 4096), 16, w_off[j] + kbytes, 0, 0, 0);
+            lds_dma16(wrs, wdst + j * PASS_BYTES, w_off[j] + kbytes);
         if (MODE != 2) {
             const int sgn = MODE == 0 ? 1 : -1;
             const int delta = (sgn * (t_kh * p.Wi + t_kw) * (int)p.ldx + t_c0 * CH) * ESZ;      // wave-uniform
@@ -143,7 +150,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
                 const bool ok = (unsigned)sh < (unsigned)p.Hi && (unsigned)sw < (unsigned)p.Wi;
                 uint32_t off = (uint32_t)(x_base[j] + delta);
                 off = ok ? off : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(xdst + j * 4096), 16, off, 0, 0, 0);
+                lds_dma16(xrs, xdst + j * PASS_BYTES, off);
             }
             t_c0 += 8;
             if (t_c0 >= p.cpt) { t_c0 = 0; if (++t_kw == p.ks) { t_kw = 0; ++t_kh; } }
@@ -166,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
                 }
                 uint32_t off = (uint32_t)(((x_base[j] + sh * p.Wi + sw) * (int)p.ldx + cc * CH) * ESZ);
                 off = ok ? off : OOB;
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(xdst + j * 4096), 16, off, 0, 0, 0);
+                lds_dma16(xrs, xdst + j * PASS_BYTES, off);
             }
         }
     };
@@ -188,32 +195,71 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
     for (int j = 0; j < TM; ++j) { const int row = wm * (TM * 32) + j * 32 + fr; rd_x[j] = BN * 128 + row * 128; sw_x[j] = (row >> 1) & 7; }
 
     auto compute = [&](int buf) {
+        // fragment reads of sub-step s+1 are issued BEFORE the MFMAs of sub-step s (two fragment register sets),
+        // so the ~128-cycle LDS latency hides under the 4-MFMA cluster instead of idling the matrix pipe
         const char* tb = smem + buf * BUF_BYTES;
+        uint4 wf[2][TN], xf[2][TM];
+#pragma unroll
+        for (int i = 0; i < TN; ++i) wf[0][i] = *reinterpret_cast<const uint4*>(tb + rd_w[i] + ((fh ^ sw_w[i]) << 4));
+#pragma unroll
+        for (int j = 0; j < TM; ++j) xf[0][j] = *reinterpret_cast<const uint4*>(tb + rd_x[j] + ((fh ^ sw_x[j]) << 4));
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            const int c = 2 * s + fh;
-            uint4 wf[TN], xf[TM];
+            const int cur = s & 1, nxt = cur ^ 1;
+            if (s < 3) {
+                const int c = 2 * (s + 1) + fh;
 #pragma unroll
-            for (int i = 0; i < TN; ++i) wf[i] = *reinterpret_cast<const uint4*>(tb + rd_w[i] + ((c ^ sw_w[i]) << 4));
+                for (int i = 0; i < TN; ++i) wf[nxt][i] = *reinterpret_cast<const uint4*>(tb + rd_w[i] + ((c ^ sw_w[i]) << 4));
 #pragma unroll
-            for (int j = 0; j < TM; ++j) xf[j] = *reinterpret_cast<const uint4*>(tb + rd_x[j] + ((c ^ sw_x[j]) << 4));
+                for (int j = 0; j < TM; ++j) xf[nxt][j] = *reinterpret_cast<const uint4*>(tb + rd_x[j] + ((c ^ sw_x[j]) << 4));
+            }
+            __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ABOVE the MFMA cluster (hipcc otherwise sinks it)
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
-                for (int j = 0; j < TM; ++j) acc[i][j] = Mma<T>::run(wf[i], xf[j], acc[i][j]);
+                for (int j = 0; j < TM; ++j) acc[i][j] = Mma<T>::run(wf[cur][i], xf[cur][j], acc[i][j]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
     const int KT = p.KT;
-    load_tiles(0, 0);
-    __syncthreads();                       // (drains vmcnt: the DMA of tile 0 has landed for every wave)
-
-    for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
-        // buffer buf^1 was last read in step kt-1, which every wave finished before the barrier below
-        if (kt + 1 < KT) load_tiles(kt + 1, buf ^ 1);
-        compute(buf);
-        __syncthreads();                   // vmcnt(0) + barrier: tile kt+1 is in LDS, tile kt no longer needed
+    if constexpr (NSTAGE == 2) {
+        load_tiles(0, 0);
+        wait_vmcnt<0>();
+        __syncthreads();                       // the DMA of tile 0 has landed for every wave
+        for (int kt = 0; kt < KT; ++kt) {
+            const int buf = kt & 1;
+            // buffer buf^1 was last read in step kt-1, which every wave finished before the barrier below
+            if (kt + 1 < KT) load_tiles(kt + 1, buf ^ 1);
+            compute(buf);
+            wait_vmcnt<0>();                   // (asm LDS-DMA is invisible to hipcc: the wait is ours)
+            __syncthreads();                   // tile kt+1 is in LDS, tile kt no longer needed
+        }
+    } else {
+        // 3-stage ring.  Each wave issues JW+JX LDS-DMA instructions per tile, in order; "vmcnt(JW+JX)" therefore
+        // means "everything except the youngest tile has landed".  The barrier is the raw s_barrier: __syncthreads()
+        // would add vmcnt(0) and drain the tile that is meant to stay in flight.
+        constexpr int PER_TILE = JW + JX;
+        load_tiles(0, 0);
+        if (KT > 1) {
+            load_tiles(1, 1);
+            wait_vmcnt<PER_TILE>();
+        } else {
+            wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        int cur = 0, nxt2 = 2;                 // stage holding tile kt, stage that will receive tile kt+2
+        for (int kt = 0; kt < KT; ++kt) {
+            // stage nxt2 held tile kt-1: every wave finished reading it before the barrier that ended step kt-1
+            if (kt + 2 < KT) load_tiles(kt + 2, nxt2);
+            compute(cur);
+            // tile kt+1 must have landed (for every wave) before step kt+1; tile kt+2 may stay in flight
+            if (kt + 2 < KT) wait_vmcnt<PER_TILE>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            cur = cur == 2 ? 0 : cur + 1;
+            nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
+        }
     }
 
     // ---- fused epilogue ------------------------------------------------------
@@ -260,29 +306,29 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
 #endif
 }
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int NT = 256, int NSTAGE = 2>
 static int launch_conv(const ConvP& p, hipStream_t stream) {
-    const size_t lds = 2 * (size_t)(BM + BN) * 128;
+    const size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
     ConvP q = p;
     q.mtiles = (p.M + BM - 1) / BM;
     q.ntiles = (p.N + BN - 1) / BN;
     const int grid = q.mtiles * q.ntiles;
     ProfScope prof(p.transposed ? PROF_CONV_DGRAD : PROF_CONV_FWD, 2.0 * (double)p.M * (double)p.N * (double)p.taps * (double)p.Cin, stream);
     const int mode = !p.fast ? 2 : (!p.transposed ? 0 : (p.stride == 1 ? 1 : 2));
-    if (mode == 0) hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 0>), dim3(grid), dim3(256), lds, stream, q);
-    else if (mode == 1) hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 1>), dim3(grid), dim3(256), lds, stream, q);
-    else hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 2>), dim3(grid), dim3(256), lds, stream, q);
+    if (mode == 0) hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 0, NT, NSTAGE>), dim3(grid), dim3(NT), lds, stream, q);
+    else if (mode == 1) hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 1, NT, NSTAGE>), dim3(grid), dim3(NT), lds, stream, q);
+    else hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 2, NT, NSTAGE>), dim3(grid), dim3(NT), lds, stream, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "conv_gemm launch");
     return PSG_OK;
 }
 
-template <typename T, int BM, int BN>
+template <typename T, int BM, int BN, int NT = 256, int NSTAGE = 2>
 static int set_conv_attrs() {
-    const int lds = 2 * (BM + BN) * 128;
-    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const int lds = NSTAGE * (BM + BN) * 128;
+    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 0, NT, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 1, NT, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 2, NT, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     return PSG_OK;
 }
 
@@ -299,6 +345,8 @@ int psg_conv_init_attrs(void) {
     if ((rc = set_conv_attrs<bf16_t, 128, 64>())) return rc;
     if ((rc = set_conv_attrs<float, 64, 64>())) return rc;
     if ((rc = set_conv_attrs<bf16_t, 64, 64>())) return rc;
+    if ((rc = set_conv_attrs<float, 256, 128, 512, 3>())) return rc;
+    if ((rc = set_conv_attrs<bf16_t, 256, 128, 512, 3>())) return rc;
     return PSG_OK;
 }
 
@@ -361,17 +409,25 @@ int psg_conv_fwd(const psg_conv_desc* d, psg_stream_t stream) {
     hipStream_t s = (hipStream_t)stream;
     int BM = 128, BN = 128;
     {
-        const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
-        const double eff[3] = {1.0, 0.78, 0.55};          // measured relative MFMA efficiency of the tile shapes
+        static int force = -2;                             // PSG_CONV_TILE=0..3 pins a candidate (kernel A/B runs)
+        if (force == -2) { const char* e = getenv("PSG_CONV_TILE"); force = e ? atoi(e) : -1; }
+        const int cand[4][2] = {{256, 128}, {128, 128}, {128, 64}, {64, 64}};
+        const double eff[4] = {0.90, 1.0, 0.78, 0.55};     // measured relative MFMA efficiency of the tile shapes
+        const double slots_of[4] = {256.0, 512.0, 512.0, 512.0};   // resident workgroups on the chip
         double best = -1.0;
-        for (int c = 0; c < 3; ++c) {
+        for (int c = 0; c < 4; ++c) {
             const double tiles = (double)((M + cand[c][0] - 1) / cand[c][0]) * (double)((d->Cout + cand[c][1] - 1) / cand[c][1]);
             const double useful = (double)M * d->Cout / (tiles * cand[c][0] * cand[c][1]);
-            const double slots = 512.0;                    // 256 CUs x 2 resident workgroups
-            const double waves = ceil(tiles / slots);
-            const double score = useful * (tiles / (waves * slots)) * eff[c];
+            const double waves = ceil(tiles / slots_of[c]);
+            double score = useful * (tiles / (waves * slots_of[c])) * eff[c];
+            if (c == 0 && p.KT < 4) score = 0.0;           // the 3-stage ring needs a few K steps to pay off
+            if (force >= 0) score = (c == force) ? 1.0 : 0.0;
             if (score > best) { best = score; BM = cand[c][0]; BN = cand[c][1]; }
         }
+    }
+    if (BM == 256) {
+        if (d->dtype == PSG_F32) return launch_conv<float, 256, 128, 512, 3>(p, s);
+        return launch_conv<bf16_t, 256, 128, 512, 3>(p, s);
     }
     if (d->dtype == PSG_F32) {
         if (BM == 128 && BN == 128) return launch_conv<float, 128, 128>(p, s);

@@ -5,6 +5,7 @@
 #include <stdio.h>
 #include <stdarg.h>
 #include <math.h>
+#include <stdlib.h>
 
 #include "../../include/psg_hip.h"
 
@@ -137,6 +138,22 @@ __device__ __forceinline__ float block_sum(float v, float* red) {
     for (int i = 0; i < nw; ++i) r += red[i];
     return r;
 }
+
+// ---- LDS-DMA (buffer_load_dwordx4 ... lds) issued from inline asm ---------------------------------------
+// hipcc tracks the builtin form as an LDS store and drains it with vmcnt(0) before the next ds_read, which
+// defeats multi-stage rings; the asm form is invisible to its waitcnt pass, so EVERY wait for these loads is
+// placed by hand (s_waitcnt vmcnt(N) + barrier before the tile is read).  Each lane moves 16 bytes from
+// `rsrc` base + voff (out-of-range => zeros) to LDS address lds_base + lane*16; lds_base must be wave-uniform.
+// M0 is written in the same statement that uses it (the compiler does not preserve it across statements).
+__device__ __forceinline__ u32x4 make_rsrc(const void* base, uint32_t bytes) {
+    const uint64_t a = reinterpret_cast<uint64_t>(base);
+    u32x4 r = {(uint32_t)a, (uint32_t)(a >> 32) & 0xFFFFu, bytes, 0x00020000u};
+    return r;
+}
+__device__ __forceinline__ void lds_dma16(const u32x4& rsrc, uint32_t lds_base, uint32_t voff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_base), "v"(voff), "s"(rsrc) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // exact n / d for n < 2^24 using a float reciprocal and one correction step
 __device__ __forceinline__ int fastdiv(int n, int d, float inv_d) {

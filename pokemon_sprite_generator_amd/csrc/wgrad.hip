@@ -77,8 +77,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
 
     constexpr uint32_t OOB = 0x80000000u;          // extents are < 2 GiB (checked on the host)
     constexpr int ESZ = (int)sizeof(T);
-    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.x), 0, p.x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.dy), 0, p.dy_bytes, 0x00020000);
+    const u32x4 xrs = make_rsrc(p.x, p.x_bytes);
+    const u32x4 yrs = make_rsrc(p.dy, p.dy_bytes);
     // Per-row "odometer": (m, ho, wo, byte offsets) of each staged pixel row advance by BKP pixels per K step
     // with adds / compares / selects only (no integer multiply or divide in the loop).
     const int ldxB = (int)p.ldx * ESZ;
@@ -96,12 +96,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
         r_pix[j] = b * SB + r_ho[j] * SH + r_wo[j] * SW;
         r_a[j] = (m * (int)p.lddy + a_co) * ESZ;
     }
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
-    const int lds_wave = __builtin_amdgcn_readfirstlane(wave) * 1024;      // this wave's 1 KiB slot inside a pass
+    typedef __attribute__((address_space(3))) char* lds_ptr_t;
+    // this wave's 1 KiB slot inside a pass (LDS byte address, wave-uniform).  The DMA is issued from inline asm
+    // (psg_common.h: lds_dma16) so hipcc does not drain it before the MFMA phase; waits are placed by hand.
+    const uint32_t lds_wave = (uint32_t)(size_t)(lds_ptr_t)smem + (uint32_t)__builtin_amdgcn_readfirstlane(wave) * 1024u;
     constexpr int PASS_BYTES = RPP * ROWB;                                  // = 4096
     auto load_tiles = [&](int buf) {   // DMA the rows at the current odometer state into LDS buffer buf, then advance
-        char* adst = smem + buf * 2 * TILE_BYTES + lds_wave;
-        char* bdst = adst + TILE_BYTES;
+        const uint32_t adst = lds_wave + (uint32_t)buf * 2 * TILE_BYTES;
+        const uint32_t bdst = adst + TILE_BYTES;
 #pragma unroll
         for (int j = 0; j < NPASS; ++j) {
             const bool m_ok = r_m[j] < p.M;
@@ -109,8 +111,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
             const int sh = r_ho[j] * p.stride - p.pad + b_kh, sw = r_wo[j] * p.stride - p.pad + b_kw;
             const bool ok = m_ok && b_ok && (unsigned)sh < (unsigned)p.Hi && (unsigned)sw < (unsigned)p.Wi;
             const uint32_t boff = ok ? (uint32_t)(r_pix[j] + b_const) : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(yrs, (lds_ptr_t)(adst + j * PASS_BYTES), 16, aoff, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(xrs, (lds_ptr_t)(bdst + j * PASS_BYTES), 16, boff, 0, 0, 0);
+            lds_dma16(yrs, adst + j * PASS_BYTES, aoff);
+            lds_dma16(xrs, bdst + j * PASS_BYTES, boff);
             // advance by BKP pixels
             r_m[j] += BKP; r_a[j] += a_step;
             int wo = r_wo[j] + od_dW;
@@ -133,7 +135,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     if (nsteps > 0) load_tiles(0);
-    __syncthreads();                       // drains vmcnt: tile 0 has landed
+    wait_vmcnt<0>();
+    __syncthreads();                       // tile 0 has landed for every wave
 
     for (int st = 0; st < nsteps; ++st) {
         const int buf = st & 1;
@@ -185,7 +188,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
                     for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
             }
         }
-        __syncthreads();                   // vmcnt(0) + barrier: next tile landed, this one no longer needed
+        wait_vmcnt<0>();                   // AFTER the MFMA phase: the DMA of the next tile overlapped it
+        __syncthreads();                   // next tile landed, this one no longer needed
     }
 
     // partial slab: ws[split][co][q]
