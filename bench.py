@@ -29,6 +29,19 @@ PEAK_F32 = 157.3e12                     # fp32 matrix (= vector) rate
 KINDS = ["conv_gemm(fwd gather)", "conv_gemm(dgrad gather)", "wgrad", "attention", "groupnorm"]
 
 
+def _host_cores():
+    """CPU cores this process may really use: affinity mask capped by the cgroup quota (a GPU box hands
+    out a CPU share; torch.get_num_threads() reports the whole machine and oversubscribes)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:                    # noqa: BLE001
+        pass
+    return max(1, min(n, 64))
+
+
 def cpu_baseline(seconds_budget=25.0):
     """The oracle (CPU restatement of the reference path) timed on this host's cores on a bounded
     sample of the same workload: forward+backward+AdamW of the full-width U-Net at batch 2."""
@@ -56,7 +69,8 @@ def cpu_baseline(seconds_budget=25.0):
     t = torch.randint(0, 1000, (B,), generator=g)
     noise = torch.randn(B, 8, 27, 27, generator=g)
     tables = O.cosine_clipped_tables()
-    cores = torch.get_num_threads()
+    cores = _host_cores()
+    torch.set_num_threads(cores)
     times = []
     t_start = time.time()
     m = {k: torch.zeros_like(v) for k, v in sd.items() if not k.endswith("emb_coeff")}

@@ -257,7 +257,7 @@ def train_step_grads(sd, latents, text_emb, t, noise, tables, num_heads=8, param
         total += g.norm(2).item() ** 2
     total = total ** 0.5
     return {
-        "loss": float(loss),
+        "loss": float(loss.detach()),
         "eps_hat": eps_hat.detach(),
         "noisy": noisy,
         "grads": dict(zip(keys, grads)),

@@ -46,10 +46,19 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave & 1, wc = wave >> 1;
 
-    // block -> (row tile, col tile, split); splits fastest so partial slabs of a tile are neighbours
-    int bid = blockIdx.x;
-    const int split = bid % p.splits; bid /= p.splits;
-    const int rt = bid % p.rtiles; const int qt = bid / p.rtiles;
+    // block -> (split, col tile, row tile), split SLOWEST: workgroups resident together then sweep the same pixel
+    // range (every output tile needs the same dY / X rows of that range), so operands are served from L2 instead
+    // of each tile streaming its own pixels from HBM.  XCD-aware: each XCD gets a contiguous range of logical ids.
+    int lid;
+    {
+        const int nb = gridDim.x, b0 = blockIdx.x;
+        const int q = nb >> 3, r = nb & 7, xcd = b0 & 7;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b0 >> 3);
+    }
+    const int tiles = p.rtiles * p.qtiles;
+    const int split = lid / tiles;
+    const int tix = lid - split * tiles;
+    const int rt = tix % p.rtiles, qt = tix / p.rtiles;
     const int co0 = rt * 128, q0 = qt * 128;
 
     // Tiles go global -> LDS by LDS-DMA (wave-uniform base + lane*16: whole 256/512-byte rows, unpadded).  For bf16
