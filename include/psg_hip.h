@@ -168,27 +168,33 @@ typedef struct psg_conv_desc {
 int psg_conv_fwd(const psg_conv_desc* d, psg_stream_t stream);
 
 /* Weight gradient — convolution_backward's wgrad for the same layers.
- * dw[co][ci][kh][kw] (fp32, OIHW like the parameter) = sum_m dy[m,co] * x[pix(m,kh,kw), ci]
- * (overwritten, or accumulated if accumulate != 0).  Split-K over pixels with a
- * deterministic second pass.  ws: >= psg_conv_wgrad_workspace_bytes(...). */
+ * dw (fp32) = sum_m dy[m,co] * x[pix(m,kh,kw), ci], stored in the parameter's own memory order:
+ * PSG_W_OIHW dw[co][ci][kh][kw] (torch contiguous) or PSG_W_OHWI dw[co][kh][kw][ci]
+ * (torch channels_last — the kernel's native order: no permute pass, and when the plan has a
+ * single K split the tiles are written straight into dw).  Overwritten, or accumulated if
+ * accumulate != 0.  Split-K over pixels with a deterministic fixed-order second pass.
+ * ws: >= psg_conv_wgrad_workspace_bytes(...) (0 bytes / NULL allowed when that returns 0). */
+enum psg_w_layout { PSG_W_OIHW = 0, PSG_W_OHWI = 1 };
 typedef struct psg_wgrad_desc {
     int32_t dtype;
     int32_t B, Hi, Wi, Cin, Ho, Wo, Cout, ksize, stride, pad;
     int32_t accumulate;
+    int32_t dw_layout;  /* psg_w_layout of dw */
+    int32_t reserved0;
     int64_t ldx, lddy;
     const void* x;    /* forward input  [B,Hi,Wi,Cin] */
     const void* dy;   /* output grad    [B,Ho,Wo,Cout] */
-    float* dw;        /* [Cout, Cin, k, k] fp32 */
+    float* dw;        /* Cout*Cin*k*k fp32 in dw_layout order */
     void* ws;
     int64_t ws_bytes;
 } psg_wgrad_desc;
 int psg_conv_wgrad(const psg_wgrad_desc* d, psg_stream_t stream);
 int64_t psg_conv_wgrad_workspace_bytes(const psg_wgrad_desc* d);
 
-/* fp32 OIHW master weight -> prepared forward weight wf [O][Kpad] with k=(kh,kw,ci) and prepared
+/* fp32 master weight (w_layout: PSG_W_OIHW or PSG_W_OHWI memory order) -> prepared forward weight wf [O][Kpad] with k=(kh,kw,ci) and prepared
  * data-gradient weight wd [I][Kpad'] with k=(kh,kw,co) (either may be NULL); zero K padding.
  * Returns Kpad for (ksize*ksize*C) via psg_kpad(). */
-int psg_prep_weight(const float* w, void* wf, void* wd, int O, int I, int ksize, int dtype,
+int psg_prep_weight(const float* w, int w_layout, void* wf, void* wd, int O, int I, int ksize, int dtype,
                     psg_stream_t stream);
 int64_t psg_kpad(int64_t K, int dtype);
 

@@ -9,11 +9,11 @@ any op without the built library raises (no CPU fallback).
 from ._lib import LIB_PATH, PsgError
 from .scheduler import NoiseScheduler
 from .unet import CrossAttentionBlock, ResBlock, TimestepEmbedding, UNet, UNetBlock
-from .optim import FusedAdamW, GradArena
+from .optim import FusedAdamW, GradArena, ParamArena
 from .ddp import BucketedAllReduce
 from .trainer import DiffusionStepper, DiffusionTrainer, ImprovedDiffusionTrainer
 
 __all__ = ["UNet", "UNetBlock", "ResBlock", "CrossAttentionBlock", "TimestepEmbedding", "NoiseScheduler",
-           "ImprovedDiffusionTrainer", "DiffusionTrainer", "DiffusionStepper", "FusedAdamW", "GradArena",
+           "ImprovedDiffusionTrainer", "DiffusionTrainer", "DiffusionStepper", "FusedAdamW", "GradArena", "ParamArena",
            "BucketedAllReduce", "PsgError", "LIB_PATH"]
 __version__ = "0.1.0"

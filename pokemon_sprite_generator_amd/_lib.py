@@ -38,6 +38,7 @@ class WgradDesc(C.Structure):
         ("dtype", C.c_int32), ("B", C.c_int32), ("Hi", C.c_int32), ("Wi", C.c_int32), ("Cin", C.c_int32),
         ("Ho", C.c_int32), ("Wo", C.c_int32), ("Cout", C.c_int32),
         ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("accumulate", C.c_int32),
+        ("dw_layout", C.c_int32), ("reserved0", C.c_int32),
         ("ldx", C.c_int64), ("lddy", C.c_int64),
         ("x", c_void_p), ("dy", c_void_p), ("dw", c_void_p), ("ws", c_void_p), ("ws_bytes", C.c_int64),
     ]
@@ -68,7 +69,7 @@ SIGNATURES = {
     "psg_conv_fwd": (c_int, [C.POINTER(ConvDesc), c_void_p]),
     "psg_conv_wgrad": (c_int, [C.POINTER(WgradDesc), c_void_p]),
     "psg_conv_wgrad_workspace_bytes": (c_int64, [C.POINTER(WgradDesc)]),
-    "psg_prep_weight": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "psg_prep_weight": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "psg_kpad": (c_int64, [c_int64, c_int]),
     "psg_colsum": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "psg_colsum_workspace_bytes": (c_int64, [c_int64, c_int, c_int]),

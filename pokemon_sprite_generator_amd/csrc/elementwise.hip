@@ -344,7 +344,7 @@ __global__ void clip_scale_kernel(float* __restrict__ g, int64_t n, const float*
 // weight preparation: fp32 OIHW -> [O][Kpad] (kh,kw,ci) and [I][Kpad'] (kh,kw,co)
 // ---------------------------------------------------------------------------
 template <typename T>
-__global__ void prep_weight_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd,
+__global__ void prep_weight_kernel(const float* __restrict__ w, int ohwi, T* __restrict__ wf, T* __restrict__ wd,
                                    int O, int I, int taps, int64_t kpf, int64_t kpd) {
     // One workgroup per (32 co) x (32 ci) x taps tile: W is read ONCE, coalesced (32*taps contiguous floats per
     // co row), transposed through LDS, and both prepared layouts are written in 64-byte runs.
@@ -352,9 +352,17 @@ __global__ void prep_weight_kernel(const float* __restrict__ w, T* __restrict__ 
     const int ci0 = blockIdx.x * 32, co0 = blockIdx.y * 32;
     const int nci = min(32, I - ci0), nco = min(32, O - co0);
     const int run = nci * taps;
-    for (int e = threadIdx.x; e < nco * run; e += blockDim.x) {
-        const int r = e / run, c = e - r * run;
-        t[r][c] = w[((int64_t)(co0 + r) * I + ci0) * taps + c];
+    if (ohwi) {                                        // w[co][tap][ci]: nci-float runs
+        for (int e = threadIdx.x; e < nco * taps * 32; e += blockDim.x) {
+            const int ci = e & 31, rt = e >> 5;
+            const int tap = rt % taps, r = rt / taps;
+            if (ci < nci) t[r][ci * taps + tap] = w[((int64_t)(co0 + r) * taps + tap) * I + ci0 + ci];
+        }
+    } else {                                           // w[co][ci][tap]: nci*taps-float runs
+        for (int e = threadIdx.x; e < nco * run; e += blockDim.x) {
+            const int r = e / run, c = e - r * run;
+            t[r][c] = w[((int64_t)(co0 + r) * I + ci0) * taps + c];
+        }
     }
     __syncthreads();
     if (wf) {
@@ -653,16 +661,18 @@ int64_t psg_kpad(int64_t K, int dtype) {
     return (K + bk - 1) / bk * bk;
 }
 
-int psg_prep_weight(const float* w, void* wf, void* wd, int O, int I, int ksize, int dtype, psg_stream_t stream) {
+int psg_prep_weight(const float* w, int w_layout, void* wf, void* wd, int O, int I, int ksize, int dtype, psg_stream_t stream) {
     PSG_REQUIRE(w && (wf || wd), PSG_ERR_ARG, "prep_weight: null pointer");
     PSG_REQUIRE(O > 0 && I > 0 && (ksize == 1 || ksize == 3), PSG_ERR_SHAPE, "prep_weight: O=%d I=%d k=%d", O, I, ksize);
+    PSG_REQUIRE(w_layout == PSG_W_OIHW || w_layout == PSG_W_OHWI, PSG_ERR_ARG, "prep_weight: w_layout %d", w_layout);
+    const int ohwi = w_layout == PSG_W_OHWI;
     const int taps = ksize * ksize;
     const int64_t kpf = psg_kpad((int64_t)taps * I, dtype), kpd = psg_kpad((int64_t)taps * O, dtype);
     PSG_REQUIRE((O + 31) / 32 <= 65535, PSG_ERR_SHAPE, "prep_weight: O=%d too large", O);
     const dim3 g((I + 31) / 32, (O + 31) / 32);
     DISPATCH_DTYPE(dtype,
-        hipLaunchKernelGGL(prep_weight_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, w, (float*)wf, (float*)wd, O, I, taps, kpf, kpd),
-        hipLaunchKernelGGL(prep_weight_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, w, (bf16_t*)wf, (bf16_t*)wd, O, I, taps, kpf, kpd));
+        hipLaunchKernelGGL(prep_weight_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, w, ohwi, (float*)wf, (float*)wd, O, I, taps, kpf, kpd),
+        hipLaunchKernelGGL(prep_weight_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, w, ohwi, (bf16_t*)wf, (bf16_t*)wd, O, I, taps, kpf, kpd));
     PSG_LAUNCH_CHECK("prep_weight");
     return PSG_OK;
 }

@@ -245,6 +245,16 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
     }
 }
 
+// native order (dw[co][q], q = tap*Cin + ci): dw (+)= sum_s ws[s], float4, fixed order
+__global__ void wgrad_sum_kernel(const float* __restrict__ ws, float* __restrict__ dw, int64_t n4, int splits, int accumulate) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 a = reinterpret_cast<const f32x4*>(ws)[i];
+        for (int s = 1; s < splits; ++s) a += reinterpret_cast<const f32x4*>(ws)[i + (int64_t)s * n4];
+        if (accumulate) a += reinterpret_cast<const f32x4*>(dw)[i];
+        reinterpret_cast<f32x4*>(dw)[i] = a;
+    }
+}
+
 static void wgrad_plan(const psg_wgrad_desc* d, WgP& p) {
     const int BKP = d->dtype == PSG_BF16 ? 64 : 32;
     p.M = d->B * d->Ho * d->Wo;
@@ -260,6 +270,10 @@ static void wgrad_plan(const psg_wgrad_desc* d, WgP& p) {
     if (want < 1) want = 1;
     p.steps_per_split = (total_steps + want - 1) / want;
     p.splits = (total_steps + p.steps_per_split - 1) / p.steps_per_split;
+}
+// tiles land directly in dw: native order, one split, no accumulation
+static bool wgrad_direct(const psg_wgrad_desc* d, const WgP& p) {
+    return (d->dw_layout == PSG_W_OHWI || p.taps == 1) && p.splits == 1 && !d->accumulate;
 }
 
 }  // namespace psg
@@ -284,6 +298,7 @@ static int wgrad_check(const psg_wgrad_desc* d) {
     PSG_REQUIRE(d->Cin % CH == 0 && d->Cout % CH == 0, PSG_ERR_SHAPE, "wgrad: Cin=%d Cout=%d must be multiples of %d", d->Cin, d->Cout, CH);
     PSG_REQUIRE(d->ldx >= d->Cin && d->ldx % CH == 0 && d->lddy >= d->Cout && d->lddy % CH == 0, PSG_ERR_SHAPE, "wgrad: row strides");
     PSG_REQUIRE((int64_t)d->B * d->Ho * d->Wo < (1 << 24) && (int64_t)d->B * d->Hi * d->Wi < (1ll << 30), PSG_ERR_SHAPE, "wgrad: too many pixels");
+    PSG_REQUIRE(d->dw_layout == PSG_W_OIHW || d->dw_layout == PSG_W_OHWI, PSG_ERR_ARG, "wgrad: dw_layout %d", d->dw_layout);
     return PSG_OK;
 }
 
@@ -291,18 +306,23 @@ int64_t psg_conv_wgrad_workspace_bytes(const psg_wgrad_desc* d) {
     if (wgrad_check(d) != PSG_OK) return -1;
     WgP p;
     wgrad_plan(d, p);
-    return (int64_t)p.splits * d->Cout * p.Q * sizeof(float);
+    return wgrad_direct(d, p) ? 0 : (int64_t)p.splits * d->Cout * p.Q * sizeof(float);
 }
 
 int psg_conv_wgrad(const psg_wgrad_desc* d, psg_stream_t stream) {
     int rc = wgrad_check(d);
     if (rc) return rc;
-    PSG_REQUIRE(d->x && d->dy && d->dw && d->ws, PSG_ERR_ARG, "wgrad: null pointer");
-    PSG_REQUIRE(aligned16(d->x) && aligned16(d->dy) && aligned16(d->ws), PSG_ERR_ALIGN, "wgrad: x/dy/ws must be 16-byte aligned");
+    PSG_REQUIRE(d->x && d->dy && d->dw, PSG_ERR_ARG, "wgrad: null pointer");
+    PSG_REQUIRE(aligned16(d->x) && aligned16(d->dy) && aligned16(d->dw), PSG_ERR_ALIGN, "wgrad: x/dy/dw must be 16-byte aligned");
     WgP p;
     wgrad_plan(d, p);
-    PSG_REQUIRE(d->ws_bytes >= (int64_t)p.splits * d->Cout * p.Q * (int64_t)sizeof(float), PSG_ERR_WORKSPACE, "wgrad: workspace too small");
-    p.x = d->x; p.dy = d->dy; p.ws = (float*)d->ws; p.ldx = d->ldx; p.lddy = d->lddy;
+    const bool direct = wgrad_direct(d, p);
+    const bool native = d->dw_layout == PSG_W_OHWI || p.taps == 1;
+    if (!direct) {
+        PSG_REQUIRE(d->ws && aligned16(d->ws), PSG_ERR_ARG, "wgrad: workspace missing or not 16-byte aligned");
+        PSG_REQUIRE(d->ws_bytes >= (int64_t)p.splits * d->Cout * p.Q * (int64_t)sizeof(float), PSG_ERR_WORKSPACE, "wgrad: workspace too small");
+    }
+    p.x = d->x; p.dy = d->dy; p.ws = direct ? d->dw : (float*)d->ws; p.ldx = d->ldx; p.lddy = d->lddy;
     p.B = d->B; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
     p.ks = d->ksize; p.stride = d->stride; p.pad = d->pad;
     p.inv_HoWo = 1.0f / (float)(d->Ho * d->Wo); p.inv_Wo = 1.0f / (float)d->Wo;
@@ -321,8 +341,15 @@ int psg_conv_wgrad(const psg_wgrad_desc* d, psg_stream_t stream) {
         else hipLaunchKernelGGL(wgrad_kernel<float>, dim3(grid), dim3(256), 4 * 32 * 512, s, p);
     }
     PSG_LAUNCH_CHECK("wgrad");
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(d->Cout, (d->Cin + 255) / 256), dim3(256), 0, s, (const float*)d->ws, d->dw,
-                       d->Cout, d->Cin, p.taps, p.splits, d->accumulate);
+    if (direct) return PSG_OK;
+    if (native) {                                  // Cout*Q is a multiple of 16 (Cin, Cout multiples of 4)
+        const int64_t n4 = (int64_t)d->Cout * p.Q / 4;
+        const int g = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+        hipLaunchKernelGGL(wgrad_sum_kernel, dim3(g), dim3(256), 0, s, (const float*)d->ws, d->dw, n4, p.splits, d->accumulate);
+    } else {
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(d->Cout, (d->Cin + 255) / 256), dim3(256), 0, s, (const float*)d->ws, d->dw,
+                           d->Cout, d->Cin, p.taps, p.splits, d->accumulate);
+    }
     PSG_LAUNCH_CHECK("wgrad_reduce");
     return PSG_OK;
 }

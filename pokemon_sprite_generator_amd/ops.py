@@ -44,8 +44,22 @@ def _rows(t):
 # ---------------------------------------------------------------------------
 # prepared-weight cache
 # ---------------------------------------------------------------------------
+W_OIHW, W_OHWI = 0, 1
+
+
+def weight_layout(t):
+    """psg_w_layout of a weight / weight-gradient tensor's MEMORY order: OIHW (torch contiguous) or OHWI
+    (torch channels_last, the kernels' native order — optim.ParamArena stores conv weights that way);
+    None if it is neither (the caller makes a contiguous copy)."""
+    if t.is_contiguous():
+        return W_OIHW
+    if t.dim() == 4 and t.is_contiguous(memory_format=torch.channels_last):
+        return W_OHWI
+    return None
+
+
 class WeightCache:
-    """fp32 OIHW master weight -> kernel-layout weights in the compute dtype.
+    """fp32 master weight (OIHW or OHWI memory order) -> kernel-layout weights in the compute dtype.
 
     wf: [O][Kpad] with k=(kh,kw,ci) for the forward gather, wd: [I][Kpad'] with
     k=(kh,kw,co) for the data-gradient gather (psg_prep_weight).  Entries are
@@ -80,9 +94,10 @@ class WeightCache:
         wf = torch.empty((O, kpf), dtype=dtype, device=w.device)
         wd = torch.empty((I, kpd), dtype=dtype, device=w.device) if need_wd else None
         src = w.detach()
-        if not src.is_contiguous():
-            src = src.contiguous()
-        check(lib.psg_prep_weight(ptr(src), ptr(wf), ptr(wd), O, I, ks, code, stream_ptr()), "psg_prep_weight")
+        layout = weight_layout(src)
+        if layout is None:
+            src, layout = src.contiguous(), W_OIHW
+        check(lib.psg_prep_weight(ptr(src), layout, ptr(wf), ptr(wd), O, I, ks, code, stream_ptr()), "psg_prep_weight")
         cls._entries[key] = (stamp, wf, wd, w)   # keep w alive so id() stays unique
         return wf, wd
 
@@ -157,13 +172,23 @@ def _wgrad_launch(lib, dtype, x, ldx, dy, lddy, dw, geom, Cin, Cout, accumulate=
     d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout = B, Hi, Wi, Cin, Ho, Wo, Cout
     d.ksize, d.stride, d.pad, d.accumulate = ks, stride, pad, int(accumulate)
     d.ldx, d.lddy = ldx, lddy
-    d.x, d.dy, d.dw = x.data_ptr(), dy.data_ptr(), dw.data_ptr()
+    layout = weight_layout(dw)
+    out = dw
+    if layout is None:                       # exotic strides: compute contiguous, copy back
+        out, layout = torch.empty(dw.shape, dtype=dw.dtype, device=dw.device), W_OIHW
+        if accumulate:
+            out.copy_(dw)
+    d.dw_layout = layout
+    d.x, d.dy, d.dw = x.data_ptr(), dy.data_ptr(), out.data_ptr()
     need = lib.psg_conv_wgrad_workspace_bytes(C.byref(d))
     if need < 0:
         check(-1, "psg_conv_wgrad_workspace_bytes")
-    ws = _lib.workspace(need, x.device)
-    d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
+    if need > 0:
+        ws = _lib.workspace(need, x.device)
+        d.ws, d.ws_bytes = ws.data_ptr(), ws.numel()
     check(lib.psg_conv_wgrad(C.byref(d), stream_ptr()), "psg_conv_wgrad")
+    if out is not dw:
+        dw.copy_(out)
 
 
 def _colsum(lib, a, lda, R, groups, cols, dtype, out_dtype, keep2d=False, out=None, accumulate=False):

@@ -1,11 +1,16 @@
 """Gradient arena + fused clip/AdamW (reference: improved_diffusion_trainer.py:277-283, 399-413).
 
-GradArena keeps every parameter gradient in ONE flat fp32 buffer (p.grad are
-persistent views) and registers each view as a GradSink: the wgrad / column-sum
-/ GroupNorm-backward kernels write gradients straight into it.  The global L2
-norm is then one deterministic reduction (psg_sumsq_f32) instead of 478
-`.item()` syncs, clip + AdamW is fused (psg_adamw_f32) and the data-parallel
-all-reduce runs on large flat slices.
+ParamArena moves every parameter into ONE flat fp32 buffer (the nn.Parameters
+become views, state_dict keys/shapes unchanged) and stores 3x3 conv weights in
+OHWI memory order (torch channels_last): that is the order the weight-gradient
+kernel produces and the prepared forward weight wants, so no permute pass runs
+in either direction.  GradArena keeps every gradient in a second flat buffer
+with the same offsets and strides (p.grad are persistent views) and registers
+each view as a GradSink: the wgrad / column-sum / GroupNorm-backward kernels
+write gradients straight into it.  The global L2 norm is then one deterministic
+reduction (psg_sumsq_f32) instead of 478 `.item()` syncs, clip + AdamW is ONE
+launch over the flat buffers (psg_adamw_f32) and the data-parallel all-reduce
+runs on large flat slices.
 """
 import torch
 
@@ -14,25 +19,58 @@ from ._lib import check, ptr, stream_ptr
 from .ops import GradSink, WeightCache
 
 
+def _arena_offsets(params):
+    offsets, off = [], 0
+    for p in params:
+        offsets.append(off)
+        off += (p.numel() + 3) // 4 * 4              # keep every view 16-byte aligned
+    return offsets, off
+
+
+class ParamArena:
+    """Flat fp32 master copy of the parameters; `p.data` become views of it (in-place loads such as
+    load_state_dict keep the binding).  4-D weights with a spatial kernel are stored OHWI (channels_last)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("ParamArena: no trainable parameters")
+        dev = self.params[0].device
+        self.offsets, self.numel = _arena_offsets(self.params)
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o in zip(self.params, self.offsets):
+                if p.dtype != torch.float32:
+                    raise TypeError("ParamArena: master parameters must be fp32")
+                if p.dim() == 4 and p.shape[2] * p.shape[3] > 1:
+                    O, I, kh, kw = p.shape
+                    v = self.flat[o:o + p.numel()].view(O, kh, kw, I).permute(0, 3, 1, 2)
+                else:
+                    v = self.flat[o:o + p.numel()].view(p.shape)
+                v.copy_(p.data)
+                p.data = v
+        WeightCache.invalidate()
+
+    def like(self, flat, index):
+        """View of another flat buffer with parameter `index`'s offset, shape and strides."""
+        p = self.params[index]
+        return flat.as_strided(p.shape, p.stride(), self.offsets[index])
+
+
 class GradArena:
     def __init__(self, params, on_ready=None):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("GradArena: no trainable parameters")
         dev = self.params[0].device
-        self.offsets = []
-        off = 0
-        for p in self.params:
-            self.offsets.append(off)
-            off += (p.numel() + 3) // 4 * 4          # keep every view 16-byte aligned
-        self.numel = off
-        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.offsets, self.numel = _arena_offsets(self.params)
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
         self.normsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.on_ready = on_ready
         self.views = []
         GradSink.unregister_all()
         for i, (p, o) in enumerate(zip(self.params, self.offsets)):
-            v = self.flat[o:o + p.numel()].view_as(p)
+            v = self.flat.as_strided(p.shape, p.stride(), o)      # the parameter's own memory order
             self.views.append(v)
             p.grad = v
             GradSink.register(p, v, i, self._ready)
@@ -65,13 +103,68 @@ class GradArena:
 class FusedAdamW(torch.optim.Optimizer):
     """torch.optim.AdamW semantics (decoupled weight decay, bias correction, eps outside the sqrt-ratio)
     with gradient clipping folded in.  state_dict layout matches torch.optim.AdamW
-    ('step', 'exp_avg', 'exp_avg_sq' per parameter), so reference checkpoints interchange."""
+    ('step', 'exp_avg', 'exp_avg_sq' per parameter), so reference checkpoints interchange.
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
+    With `param_arena` + `grad_arena` (same parameters, same order) the whole update is one launch over
+    the flat buffers; the per-parameter state tensors are views of two more flat buffers."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, param_arena=None, grad_arena=None):
+        params = list(params)
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self._pa, self._ga = None, None
+        if param_arena is not None and grad_arena is not None:
+            same = (len(params) == len(param_arena.params) == len(grad_arena.params)
+                    and all(a is b and a is c for a, b, c in zip(params, param_arena.params, grad_arena.params))
+                    and param_arena.offsets == grad_arena.offsets)
+            if not same:
+                raise ValueError("FusedAdamW: arenas do not cover the optimizer's parameters in order")
+            self._pa, self._ga = param_arena, grad_arena
+            self._m = torch.zeros_like(param_arena.flat)
+            self._v = torch.zeros_like(param_arena.flat)
+            self._step = 0
+            for i, p in enumerate(params):
+                self.state[p] = {"step": torch.tensor(0.0), "exp_avg": param_arena.like(self._m, i),
+                                 "exp_avg_sq": param_arena.like(self._v, i)}
+
+    def _sync_steps(self):
+        if self._pa is not None:
+            for st in self.state.values():
+                st["step"].fill_(float(self._step))
+
+    def state_dict(self):
+        self._sync_steps()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        if self._pa is None:
+            return
+        steps = set()
+        for i, p in enumerate(self._pa.params):           # re-bind the loaded moments to the flat buffers
+            st = self.state[p]
+            m, v = self._pa.like(self._m, i), self._pa.like(self._v, i)
+            m.copy_(st["exp_avg"]); v.copy_(st["exp_avg_sq"])
+            st["exp_avg"], st["exp_avg_sq"] = m, v
+            st["step"] = torch.tensor(float(st["step"]))
+            steps.add(int(st["step"]))
+        if len(steps) != 1:
+            raise ValueError(f"FusedAdamW: flat update needs one common step count, checkpoint has {sorted(steps)}")
+        self._step = steps.pop()
 
     @torch.no_grad()
     def step(self, normsq=None, max_norm=0.0, skip_flag=None, grad_scale=1.0):
+        nptr = ptr(normsq) if normsq is not None else None
+        fptr = ptr(skip_flag) if skip_flag is not None else None
+        if self._pa is not None:
+            group = self.param_groups[0]
+            b1, b2 = group["betas"]
+            lib = _lib.init(self._pa.flat.device.index)
+            self._step += 1
+            check(lib.psg_adamw_f32(ptr(self._pa.flat), ptr(self._ga.flat), ptr(self._m), ptr(self._v), self._pa.numel,
+                                    float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
+                                    self._step, nptr, float(max_norm), fptr, stream_ptr()), "psg_adamw_f32")
+            WeightCache.invalidate()
+            return
         lib = None
         for group in self.param_groups:
             b1, b2 = group["betas"]
@@ -86,9 +179,10 @@ class FusedAdamW(torch.optim.Optimizer):
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                 st["step"] += 1
-                g = p.grad if p.grad.is_contiguous() else p.grad.contiguous()
+                g = p.grad
+                if g.stride() != p.stride():               # the kernel walks raw memory: same order required
+                    g = torch.empty_like(p).copy_(g)
                 check(lib.psg_adamw_f32(ptr(p), ptr(g), ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]), p.numel(), float(group["lr"]),
                                         float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), int(st["step"]),
-                                        ptr(normsq) if normsq is not None else None, float(max_norm),
-                                        ptr(skip_flag) if skip_flag is not None else None, stream_ptr()), "psg_adamw_f32")
+                                        nptr, float(max_norm), fptr, stream_ptr()), "psg_adamw_f32")
         WeightCache.invalidate()     # parameters changed through raw pointers

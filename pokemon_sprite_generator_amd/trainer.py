@@ -22,7 +22,7 @@ import torch
 from . import _lib
 from ._lib import check, ptr, stream_ptr
 from .ddp import BucketedAllReduce
-from .optim import FusedAdamW, GradArena
+from .optim import FusedAdamW, GradArena, ParamArena
 from .scheduler import NoiseScheduler
 from .unet import UNet
 
@@ -56,10 +56,12 @@ class DiffusionStepper:
             raise _lib.PsgError("DiffusionStepper needs the U-Net on a GPU (HIP path only)")
         self.lib = _lib.init(self.device.index if self.device.index is not None else torch.cuda.current_device())
         self.reducer = None
+        self.params = ParamArena(unet.parameters())        # flat fp32 masters, conv weights OHWI
         self.arena = GradArena(unet.parameters(), on_ready=lambda i: self.reducer.on_ready(i) if self.reducer is not None else None)
         # Adam (non-decoupled decay) is torch's when asked for (:285-291); AdamW is the fused kernel (:277-283)
         if optimizer_type == "adamw":
-            self.optimizer = FusedAdamW(self.arena.params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
+            self.optimizer = FusedAdamW(self.arena.params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
+                                        param_arena=self.params, grad_arena=self.arena)
         else:
             self.optimizer = torch.optim.Adam(self.arena.params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         if distributed is None:

@@ -248,6 +248,37 @@ def test_conv_fwd_dgrad_wgrad(psg, dtype, B, H, Cin, Cout, ks, stride):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,Cin,Cout,stride,uses", [(2, 9, 64, 96, 1, 1), (3, 14, 160, 320, 2, 1), (40, 27, 32, 64, 1, 2)])
+def test_conv_ohwi_master_weights(psg, dtype, B, H, Cin, Cout, stride, uses):
+    """Conv weights stored channels_last (OHWI, optim.ParamArena's order): prepared weights and the weight
+    gradient (direct single-split write, split-K sum, and the accumulate path of a weight used twice through a
+    GradSink) must equal the OIHW results; the gradient comes back in the parameter's own memory order."""
+    from pokemon_sprite_generator_amd import ops, GradArena
+    name = f"ohwi{B}.{H}.{Cin}.{Cout}.{stride}"
+    x = _q(h((B, Cin, H, H), name + "x", 1.2), dtype).requires_grad_(True)
+    w = _q(h((Cout, Cin, 3, 3), name + "w", math.sqrt(3.0 / (Cin * 9))), dtype).requires_grad_(True)
+    ref = F.conv2d(x, w, None, stride=stride, padding=1)
+    gy = _q(h(tuple(ref.shape), name + "gy", 1.0), dtype)
+    (ref * float(uses)).backward(gy)
+    xd = to_cl(x.detach(), dtype).to(DEV).requires_grad_(True)
+    wd = torch.nn.Parameter(w.detach().to(DEV).contiguous(memory_format=torch.channels_last))
+    assert ops.weight_layout(wd) == ops.W_OHWI
+    arena = GradArena([wd]) if uses > 1 else None
+    if arena is not None:
+        arena.zero()
+    y = ops.conv2d(xd, wd, None, stride=stride)
+    for _ in range(uses - 1):
+        y = y + ops.conv2d(xd, wd, None, stride=stride)
+    y.backward(to_cl(gy, dtype).to(DEV))
+    tol = TOL[dtype]
+    assert maxrel(from_cl(y.cpu()), ref * float(uses)) < tol, "forward"
+    assert maxrel(from_cl(xd.grad.cpu()), x.grad) < tol, "dgrad"
+    assert wd.grad.stride() == wd.stride(), "gradient must share the parameter's memory order"
+    assert maxrel(wd.grad.cpu(), w.grad) < tol, "wgrad"
+    ops.GradSink.unregister_all()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("act", ["none", "silu", "gelu"])
 def test_linear_epilogue(psg, dtype, act):
     from pokemon_sprite_generator_amd import ops
@@ -413,3 +444,47 @@ def test_sumsq_adamw_clip(psg):
             assert maxrel(p.detach().cpu(), pr.detach()) < 2e-6, f"step {step}"
     sd = opt.state_dict()
     assert set(sd["state"][0].keys()) == {"step", "exp_avg", "exp_avg_sq"}      # torch.optim.AdamW wire format
+    ops_mod = __import__("pokemon_sprite_generator_amd.ops", fromlist=["GradSink"])
+    ops_mod.GradSink.unregister_all()
+
+
+def test_flat_arena_adamw_matches_torch(psg):
+    """ParamArena (flat masters, 3x3 weights OHWI) + GradArena + single-launch FusedAdamW == torch.optim.AdamW
+    after clip_grad_norm_; optimizer state_dict round-trips in torch's wire format (checkpoint resume)."""
+    from pokemon_sprite_generator_amd import FusedAdamW, GradArena, ParamArena, ops
+    torch.manual_seed(2)
+    shapes = [(64, 32, 3, 3), (130,), (96, 64, 1, 1), (77, 13), (5,)]
+    ps_ref = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    ps = [torch.nn.Parameter(p.detach().clone().to(DEV)) for p in ps_ref]
+    pa = ParamArena(ps)
+    assert ops.weight_layout(ps[0]) == ops.W_OHWI and ps[2].is_contiguous() and ps[0].shape == (64, 32, 3, 3)
+    for p, pr in zip(ps, ps_ref):
+        assert torch.equal(p.detach().cpu(), pr.detach())
+    ga = GradArena(ps)
+    assert ps[0].grad.stride() == ps[0].stride()
+    kw = dict(lr=3e-4, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.01)
+    opt_ref = torch.optim.AdamW(ps_ref, **kw)
+    opt = FusedAdamW(ps, param_arena=pa, grad_arena=ga, **kw)
+
+    def run(opt, steps, s0):
+        for step in range(s0, s0 + steps):
+            g0 = torch.Generator().manual_seed(100 + step)
+            gs = [torch.randn(s, generator=g0) * (3.0 if step % 2 == 0 else 0.01) for s in shapes]
+            ga.zero()
+            for p, pr, g in zip(ps, ps_ref, gs):
+                pr.grad = g.clone()
+                p.grad.copy_(g.to(DEV))
+            torch.nn.utils.clip_grad_norm_(ps_ref, max_norm=1.0)
+            opt_ref.step()
+            opt.step(normsq=ga.grad_norm_sq(), max_norm=1.0)
+            for p, pr in zip(ps, ps_ref):
+                assert maxrel(p.detach().cpu(), pr.detach()) < 2e-6, f"step {step}"
+
+    run(opt, 3, 0)
+    sd = opt.state_dict()
+    assert float(sd["state"][0]["step"]) == 3.0 and sd["state"][0]["exp_avg"].shape == (64, 32, 3, 3)
+    opt2 = FusedAdamW(ps, param_arena=pa, grad_arena=ga, **kw)            # resume into a fresh optimizer
+    opt2.load_state_dict({"state": {k: {kk: (vv.clone() if torch.is_tensor(vv) else vv) for kk, vv in v.items()} for k, v in sd["state"].items()},
+                          "param_groups": sd["param_groups"]})
+    run(opt2, 2, 3)
+    ops.GradSink.unregister_all()
