@@ -391,6 +391,65 @@ __global__ void prep_weight_kernel(const float* __restrict__ w, int ohwi, T* __r
     }
 }
 
+// OHWI master (w[co][tap][ci], the training layout) or any 1x1/linear weight: one 64co x 64ci tile of one tap per
+// workgroup.  Shift-only index math, 256-byte coalesced reads, 8/16-byte stores of 4 elements along ci (wf) and
+// along co (wd, transposed through LDS).  Needs O % 4 == 0 and I % 4 == 0.
+template <typename T>
+__global__ __launch_bounds__(256) void prep_weight_ohwi_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd,
+                                                               int O, int I, int taps, int64_t kpf, int64_t kpd) {
+    __shared__ float t[64][65];
+    const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, tap = blockIdx.z;
+    const int tid = threadIdx.x;
+    {
+        const int c = tid & 63, rr = tid >> 6;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int co = i * 4 + rr;
+            float v = 0.f;
+            if (co0 + co < O && ci0 + c < I) v = w[((int64_t)(co0 + co) * taps + tap) * I + ci0 + c];
+            t[co][c] = v;
+        }
+    }
+    __syncthreads();
+    const int q4 = (tid & 15) * 4, rq = tid >> 4;
+    if (wf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = rq + 16 * i;
+            if (co0 + co < O && ci0 + q4 < I) {
+                f32x4 v = {t[co][q4], t[co][q4 + 1], t[co][q4 + 2], t[co][q4 + 3]};
+                store4<T>(wf + (int64_t)(co0 + co) * kpf + (int64_t)tap * I + ci0 + q4, v);
+            }
+        }
+        if (blockIdx.x == 0 && tap == 0) {             // zero the K padding of these rows
+            const int64_t k0 = (int64_t)taps * I;
+            const int npad = (int)(kpf - k0);
+            for (int e = tid; e < 64 * npad; e += 256) {
+                const int r = e / npad, c = e - r * npad;
+                if (co0 + r < O) Elem<T>::st(wf + (int64_t)(co0 + r) * kpf + k0 + c, 0.f);
+            }
+        }
+    }
+    if (wd) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ci = rq + 16 * i;
+            if (ci0 + ci < I && co0 + q4 < O) {
+                f32x4 v = {t[q4][ci], t[q4 + 1][ci], t[q4 + 2][ci], t[q4 + 3][ci]};
+                store4<T>(wd + (int64_t)(ci0 + ci) * kpd + (int64_t)tap * O + co0 + q4, v);
+            }
+        }
+        if (blockIdx.y == 0 && tap == 0) {
+            const int64_t k0 = (int64_t)taps * O;
+            const int npad = (int)(kpd - k0);
+            for (int e = tid; e < 64 * npad; e += 256) {
+                const int r = e / npad, c = e - r * npad;
+                if (ci0 + r < I) Elem<T>::st(wd + (int64_t)(ci0 + r) * kpd + k0 + c, 0.f);
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------
 // column sums (bias gradient / per-sample rowadd gradient), deterministic 2-stage
 // grid: (col blocks of 64*4 columns... see launcher)
@@ -669,10 +728,19 @@ int psg_prep_weight(const float* w, int w_layout, void* wf, void* wd, int O, int
     const int taps = ksize * ksize;
     const int64_t kpf = psg_kpad((int64_t)taps * I, dtype), kpd = psg_kpad((int64_t)taps * O, dtype);
     PSG_REQUIRE((O + 31) / 32 <= 65535, PSG_ERR_SHAPE, "prep_weight: O=%d too large", O);
+    hipStream_t s = (hipStream_t)stream;
+    if ((ohwi || taps == 1) && O % 4 == 0 && I % 4 == 0 && aligned16(w) && (!wf || aligned16(wf)) && (!wd || aligned16(wd))) {
+        const dim3 g((I + 63) / 64, (O + 63) / 64, taps);
+        DISPATCH_DTYPE(dtype,
+            hipLaunchKernelGGL(prep_weight_ohwi_kernel<float>, g, dim3(256), 0, s, w, (float*)wf, (float*)wd, O, I, taps, kpf, kpd),
+            hipLaunchKernelGGL(prep_weight_ohwi_kernel<bf16_t>, g, dim3(256), 0, s, w, (bf16_t*)wf, (bf16_t*)wd, O, I, taps, kpf, kpd));
+        PSG_LAUNCH_CHECK("prep_weight");
+        return PSG_OK;
+    }
     const dim3 g((I + 31) / 32, (O + 31) / 32);
     DISPATCH_DTYPE(dtype,
-        hipLaunchKernelGGL(prep_weight_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, w, ohwi, (float*)wf, (float*)wd, O, I, taps, kpf, kpd),
-        hipLaunchKernelGGL(prep_weight_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, w, ohwi, (bf16_t*)wf, (bf16_t*)wd, O, I, taps, kpf, kpd));
+        hipLaunchKernelGGL(prep_weight_kernel<float>, dim3(g), dim3(256), 0, s, w, ohwi, (float*)wf, (float*)wd, O, I, taps, kpf, kpd),
+        hipLaunchKernelGGL(prep_weight_kernel<bf16_t>, dim3(g), dim3(256), 0, s, w, ohwi, (bf16_t*)wf, (bf16_t*)wd, O, I, taps, kpf, kpd));
     PSG_LAUNCH_CHECK("prep_weight");
     return PSG_OK;
 }

@@ -264,11 +264,29 @@ static void wgrad_plan(const psg_wgrad_desc* d, WgP& p) {
     p.qtiles = (p.Q + 127) / 128;
     const int total_steps = (p.M + BKP - 1) / BKP;
     const int tiles = p.rtiles * p.qtiles;
-    int want = (1024 + tiles - 1) / tiles;          // ~4 workgroups per CU in flight
-    const int max_splits = (total_steps + 7) / 8;   // at least 8 K steps per split
-    if (want > max_splits) want = max_splits;
-    if (want < 1) want = 1;
-    p.steps_per_split = (total_steps + want - 1) / want;
+    // Split-K choice by a makespan model: 2 workgroups (64 KB LDS each) per CU x 256 CUs = 512 slots; a launch runs
+    // in ceil(blocks/512) rounds of (steps_per_split + fixed prologue/epilogue) K steps, and every extra split adds
+    // one slab of traffic to the deterministic sum pass.  Picking the split count that merely "fills the chip"
+    // leaves e.g. 1035 blocks = 2.02 rounds (a third of the time on 11 stragglers); this picks 966 or 483 instead.
+    const int kSlots = 512;
+    const double step_us = d->dtype == PSG_BF16 ? 1.05 : 8.0, fixed_steps = 6.0;
+    const double slab_us = (double)d->Cout * p.Q * 4.0 / 4.0e6;          // one fp32 slab through HBM at ~4 TB/s
+    const bool native = d->dw_layout == PSG_W_OHWI || p.taps == 1;
+    int max_splits = (total_steps + 7) / 8;                               // at least 8 K steps per split
+    if (max_splits > 256) max_splits = 256;
+    if (max_splits < 1) max_splits = 1;
+    double best = 1e300;
+    int best_sps = total_steps;
+    for (int want = 1; want <= max_splits; ++want) {
+        const int sps = (total_steps + want - 1) / want;
+        const int sp = (total_steps + sps - 1) / sps;
+        const int64_t blocks = (int64_t)tiles * sp;
+        const double rounds = (double)((blocks + kSlots - 1) / kSlots);
+        const bool direct = native && sp == 1 && !d->accumulate;
+        const double cost = rounds * (sps + fixed_steps) * step_us + (direct ? 0.0 : (sp + 1.0) * slab_us + 3.0);
+        if (cost < best - 1e-9) { best = cost; best_sps = sps; }
+    }
+    p.steps_per_split = best_sps;
     p.splits = (total_steps + p.steps_per_split - 1) / p.steps_per_split;
 }
 // tiles land directly in dw: native order, one split, no accumulation
