@@ -10,11 +10,11 @@
 //
 // Tiling: BM pixels x BN channels per 256-thread workgroup (4 waves, 2x2), K step
 // of 8 sixteen-byte chunks (64 bf16 / 32 fp32 values, always inside one filter
-// tap when Cin % chunk-run == 0).  Operand tiles are register-staged
-// (global_load_dwordx4 issued before the MFMA phase, ds_write_b128 after it) into
-// a double-buffered, XOR-swizzled LDS image (128-byte rows; chunk ^= (row>>1)&7
+// tap when Cin % chunk-run == 0).  Operand tiles go global -> LDS by LDS-DMA
+// (buffer_load_dwordx4 ... lds issued from inline asm, hand-placed s_waitcnt vmcnt) into a
+// double-buffered, XOR-swizzled LDS image (128-byte rows; chunk ^= (row>>1)&7
 // makes the ds_read_b128 fragment reads conflict-free), one barrier per K step.
-// bf16: v_mfma_f32_32x32x16_bf16; fp32: v_mfma_f32_32x32x2_f32 (exact fp32).
+// bf16: v_mfma_f32_16x16x32_bf16; fp32: v_mfma_f32_32x32x2_f32 (exact fp32).
 // Workgroup ids are remapped XCD-aware (each XCD's L2 sees a contiguous range of
 // tiles) and rasterised in groups of 8 M-tiles sharing weight panels.
 #include "psg_common.h"
@@ -50,6 +50,13 @@ template <> struct Mma<float> {
         return c;
     }
 };
+
+// bf16 main loop: v_mfma_f32_16x16x32_bf16.  Same LDS bytes per FLOP as 32x32x16 (a fragment is 1 KiB either way)
+// but the chip sustains a higher clock on this shape under load, and the 16-pixel x 16-channel accumulator tile
+// (lane: pixel = lane&15, 4 consecutive channels 4*(lane>>4)..+3) stores 32-byte runs per pixel.
+__device__ __forceinline__ f32x4 mma16(const uint4& a, const uint4& b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
+}
 
 __device__ __forceinline__ int lds_off(int row, int chunk) {   // byte offset inside a tile of 128-byte rows
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
@@ -178,47 +185,73 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(const ConvP p) {
         }
     };
 
-    f32x16 acc[TN][TM];
+    constexpr bool FT16 = sizeof(T) == 2;                 // bf16: 16x16x32 tiles; fp32: 32x32x2 tiles
+    constexpr int NA = FT16 ? TN * 2 : TN, NB = FT16 ? TM * 2 : TM;   // fragment tiles per wave along n / m
+    constexpr int AE = FT16 ? 4 : 16;
+    typedef float AccT __attribute__((ext_vector_type(AE)));
+    AccT acc[NA][NB];
 #pragma unroll
-    for (int i = 0; i < TN; ++i)
+    for (int i = 0; i < NA; ++i)
 #pragma unroll
-        for (int j = 0; j < TM; ++j)
+        for (int j = 0; j < NB; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < AE; ++e) acc[i][j][e] = 0.f;
 
-    const int fr = lane & 31, fh = lane >> 5;
-    int rd_w[TN], rd_x[TM];          // fragment row bases (bytes), chunk swizzle key
-    int sw_w[TN], sw_x[TM];
-#pragma unroll
-    for (int i = 0; i < TN; ++i) { const int row = wn * (TN * 32) + i * 32 + fr; rd_w[i] = row * 128; sw_w[i] = (row >> 1) & 7; }
-#pragma unroll
-    for (int j = 0; j < TM; ++j) { const int row = wm * (TM * 32) + j * 32 + fr; rd_x[j] = BN * 128 + row * 128; sw_x[j] = (row >> 1) & 7; }
+    const int fr = lane & 31, fh = lane >> 5;             // 32x32 fragment coordinates (fp32 path)
+    const int l16 = lane & 15, kq = lane >> 4;            // 16x16x32 fragment coordinates (bf16 path)
+    // fragment row bases (bytes) and chunk swizzle key; tile rows step by 16 / 32, which leaves (row>>1)&7 unchanged
+    const int frow = FT16 ? l16 : fr;
+    const int rd_w = (wn * (TN * 32) + frow) * 128, rd_x = BN * 128 + (wm * (TM * 32) + frow) * 128;
+    const int swz = (frow >> 1) & 7;
+    constexpr int FSTEP = (FT16 ? 16 : 32) * 128;         // byte step between fragment tiles
 
     auto compute = [&](int buf) {
-        // fragment reads of sub-step s+1 are issued BEFORE the MFMAs of sub-step s (two fragment register sets),
-        // so the ~128-cycle LDS latency hides under the 4-MFMA cluster instead of idling the matrix pipe
         const char* tb = smem + buf * BUF_BYTES;
-        uint4 wf[2][TN], xf[2][TM];
+        if constexpr (FT16) {
+            // all 2 x (NA + NB) fragment reads of the K tile are issued up front (64 VGPRs); the MFMAs start as the
+            // first ones land and the rest of the LDS latency hides under the 2 x NA x NB MFMA stream
+            uint4 wf[2][NA], xf[2][NB];
 #pragma unroll
-        for (int i = 0; i < TN; ++i) wf[0][i] = *reinterpret_cast<const uint4*>(tb + rd_w[i] + ((fh ^ sw_w[i]) << 4));
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int co = ((4 * s2 + kq) ^ swz) << 4;
 #pragma unroll
-        for (int j = 0; j < TM; ++j) xf[0][j] = *reinterpret_cast<const uint4*>(tb + rd_x[j] + ((fh ^ sw_x[j]) << 4));
+                for (int i = 0; i < NA; ++i) wf[s2][i] = *reinterpret_cast<const uint4*>(tb + rd_w + i * FSTEP + co);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int cur = s & 1, nxt = cur ^ 1;
-            if (s < 3) {
-                const int c = 2 * (s + 1) + fh;
-#pragma unroll
-                for (int i = 0; i < TN; ++i) wf[nxt][i] = *reinterpret_cast<const uint4*>(tb + rd_w[i] + ((c ^ sw_w[i]) << 4));
-#pragma unroll
-                for (int j = 0; j < TM; ++j) xf[nxt][j] = *reinterpret_cast<const uint4*>(tb + rd_x[j] + ((c ^ sw_x[j]) << 4));
+                for (int j = 0; j < NB; ++j) xf[s2][j] = *reinterpret_cast<const uint4*>(tb + rd_x + j * FSTEP + co);
             }
-            __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ABOVE the MFMA cluster (hipcc otherwise sinks it)
+            __builtin_amdgcn_sched_barrier(0);      // keep the reads ABOVE the MFMA stream (hipcc otherwise sinks them)
 #pragma unroll
-            for (int i = 0; i < TN; ++i)
+            for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                for (int j = 0; j < TM; ++j) acc[i][j] = Mma<T>::run(wf[cur][i], xf[cur][j], acc[i][j]);
+                for (int i = 0; i < NA; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) acc[i][j] = mma16(wf[s2][i], xf[s2][j], acc[i][j]);
             __builtin_amdgcn_sched_barrier(0);
+        } else {
+            // fragment reads of sub-step s+1 are issued BEFORE the MFMAs of sub-step s (two fragment register sets),
+            // so the ~128-cycle LDS latency hides under the MFMA cluster instead of idling the matrix pipe
+            uint4 wf[2][NA], xf[2][NB];
+#pragma unroll
+            for (int i = 0; i < NA; ++i) wf[0][i] = *reinterpret_cast<const uint4*>(tb + rd_w + i * FSTEP + ((fh ^ swz) << 4));
+#pragma unroll
+            for (int j = 0; j < NB; ++j) xf[0][j] = *reinterpret_cast<const uint4*>(tb + rd_x + j * FSTEP + ((fh ^ swz) << 4));
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int cur = s & 1, nxt = cur ^ 1;
+                if (s < 3) {
+                    const int c = 2 * (s + 1) + fh;
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) wf[nxt][i] = *reinterpret_cast<const uint4*>(tb + rd_w + i * FSTEP + ((c ^ swz) << 4));
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) xf[nxt][j] = *reinterpret_cast<const uint4*>(tb + rd_x + j * FSTEP + ((c ^ swz) << 4));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NA; ++i)
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) acc[i][j] = Mma<T>::run(wf[cur][i], xf[cur][j], acc[i][j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     };
 
@@ -269,37 +302,56 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(const ConvP p) {
     T* preg = reinterpret_cast<T*>(p.preact);
     const T* dug = reinterpret_cast<const T*>(p.dact_u);
     const int HoWo = p.Ho * p.Wo;
+    auto emit = [&](int m, int b, int n, f32x4 v) {       // 4 consecutive output channels n..n+3 of pixel m
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+        if (rag) v += load4<T>(rag + (int64_t)b * p.ldra + n);
+        if (preg) store4<T>(preg + (int64_t)m * p.ldpre + n, v);
+        if (dug) {          // backward form: multiply by act'(u) of the saved pre-activation
+            const f32x4 u = load4<T>(dug + (int64_t)m * p.lddact + n);
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-        const int m = m0 + wm * (TM * 32) + j * 32 + fr;
-        if (m >= p.M) continue;
-        const int b = m / HoWo;
+            for (int e = 0; e < 4; ++e) v[e] *= act_grad(u[e], p.act);
+        } else if (p.act != PSG_ACT_NONE) {
 #pragma unroll
-        for (int i = 0; i < TN; ++i) {
+            for (int e = 0; e < 4; ++e) v[e] = act_f(v[e], p.act);
+        }
+        if (p.drop_thresh) {
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn * (TN * 32) + i * 32 + 8 * g + 4 * fh;
+            for (int e = 0; e < 4; ++e)
+                v[e] = drop_keep(p.drop_seed, (uint64_t)m * p.N + n + e, p.drop_thresh) ? v[e] * p.drop_scale : 0.f;
+        }
+        v *= p.alpha;
+        if (resg) v += load4<T>(resg + (int64_t)m * p.ldres + n);
+        store4<T>(yg + (int64_t)m * p.ldy + n, v);
+    };
+    if constexpr (FT16) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const int m = m0 + wm * (TM * 32) + j * 16 + l16;
+            if (m >= p.M) continue;
+            const int b = m / HoWo;
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int n = n0 + wn * (TN * 32) + i * 16 + 4 * kq;
                 if (n >= p.N) continue;
-                f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-                if (rag) v += load4<T>(rag + (int64_t)b * p.ldra + n);
-                if (preg) store4<T>(preg + (int64_t)m * p.ldpre + n, v);
-                if (dug) {          // backward form: multiply by act'(u) of the saved pre-activation
-                    const f32x4 u = load4<T>(dug + (int64_t)m * p.lddact + n);
+                f32x4 v = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                emit(m, b, n, v);
+            }
+        }
+    } else {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] *= act_grad(u[e], p.act);
-                } else if (p.act != PSG_ACT_NONE) {
+        for (int j = 0; j < NB; ++j) {
+            const int m = m0 + wm * (TM * 32) + j * 32 + fr;
+            if (m >= p.M) continue;
+            const int b = m / HoWo;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = act_f(v[e], p.act);
+            for (int i = 0; i < NA; ++i) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = n0 + wn * (TN * 32) + i * 32 + 8 * g + 4 * fh;
+                    if (n >= p.N) continue;
+                    f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                    emit(m, b, n, v);
                 }
-                if (p.drop_thresh) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        v[e] = drop_keep(p.drop_seed, (uint64_t)m * p.N + n + e, p.drop_thresh) ? v[e] * p.drop_scale : 0.f;
-                }
-                v *= p.alpha;
-                if (resg) v += load4<T>(resg + (int64_t)m * p.ldres + n);
-                store4<T>(yg + (int64_t)m * p.ldy + n, v);
             }
         }
     }

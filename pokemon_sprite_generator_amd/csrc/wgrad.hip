@@ -63,10 +63,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
 
     // Tiles go global -> LDS by LDS-DMA (wave-uniform base + lane*16: whole 256/512-byte rows, unpadded).  For bf16
     // the transposed fragment reads (4 consecutive pixel rows x 64-byte column windows per half-wave) are made
-    // conflict-free by XOR-ing the 16-byte chunk index with (row & 3) << 2 - applied on the SOURCE side: the lane
-    // at physical chunk (tid % CPR) of row sr fetches logical chunk sc.  (row & 3 is the same in every pass.)
+    // conflict-free by XOR-ing the 16-byte chunk index with ((row & 3) << 2) | ((row >> 2) & 3) - applied on the SOURCE
+    // side: the lane at physical chunk (tid % CPR) of row sr fetches logical chunk sc.  (Passes step 16 rows: same key.)
     const int sr = tid / CPR;
-    const int sc = sizeof(T) == 2 ? ((tid % CPR) ^ ((sr & 3) << 2)) : (tid % CPR);
+    const int sc = sizeof(T) == 2 ? ((tid % CPR) ^ (((sr & 3) << 2) | ((sr >> 2) & 3))) : (tid % CPR);
 
     // A operand (dY): column chunk -> co
     const int a_co = co0 + sc * CH;
@@ -135,13 +135,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
         }
     };
 
-    f32x16 acc[2][2];
+    // bf16: 4x4 tiles of v_mfma_f32_16x16x32_bf16 per wave (higher sustained clock than 32x32x16 at the same LDS
+    // traffic); fp32: 2x2 tiles of v_mfma_f32_32x32x2_f32
+    constexpr bool FT16 = sizeof(T) == 2;
+    constexpr int NA = FT16 ? 4 : 2, AE = FT16 ? 4 : 16;
+    typedef float AccT __attribute__((ext_vector_type(AE)));
+    AccT acc[NA][NA];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < NA; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NA; ++j)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+            for (int e = 0; e < AE; ++e) acc[i][j][e] = 0.f;
 
     if (nsteps > 0) load_tiles(0);
     wait_vmcnt<0>();
@@ -152,35 +157,41 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
         if (st + 1 < nsteps) load_tiles(buf ^ 1);      // buffer buf^1 was last read in step st-1 (barrier below)
         const char* ab = smem + buf * 2 * TILE_BYTES;
         const char* bb = ab + TILE_BYTES;
-        if constexpr (sizeof(T) == 2) {
-            // lane -> (16-lane group g, q4 = row of the 4x16 block, p4 = 4-column piece)
+        if constexpr (FT16) {
+            // Transposed fragment reads.  Lane -> (16-lane group g, q4 = row of the 4x16 block, p4 = 4-column piece):
+            // group g of k-step s2 reads pixel rows 32*s2 + 8g + {0..3} and + {4..7}, columns tile + 4*p4..+3, and
+            // lane i16 receives column i16 of those rows: element e <-> pixel 32*s2 + 8g + e, the 16x16x32 operand order.
+            // A half-wave's two blocks sit 8 rows apart in the same columns: conflict-free on this swizzled image.
+            typedef __attribute__((ext_vector_type(8))) short s16x8;
             const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
-            const int krow = (g >> 1) * 8 + q4;             // + 16*kk + 4*u
-            const int ccol = (g & 1) * 16 + p4 * 4;         // + tile column base
+            const int key0 = (q4 << 2) | ((2 * g) & 3), key1 = (q4 << 2) | ((2 * g + 1) & 3);   // swizzle keys of the 2 rows
+            const int rowb = (8 * g + q4) * ROWB + 8 * (p4 & 1);
+            const int chA = wr * 8 + (p4 >> 1), chB = wc * 8 + (p4 >> 1);      // 16-byte chunk of tile 0 (+2 per tile)
+            bf16x8 af[2][4], bf[2][4];
 #pragma unroll
-            for (int kk = 0; kk < BKP / 16; ++kk) {
-                bf16x8 af[2], bf[2];
+            for (int s2 = 0; s2 < 2; ++s2) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    // column -> (16-byte chunk, offset inside it); the chunk is XOR-swizzled with (row & 3) << 2 == q4 << 2
-                    const int colA = wr * 64 + i * 32 + ccol, colB = wc * 64 + i * 32 + ccol;
-                    const int offA = ((((colA >> 3) ^ (q4 << 2)) << 4) + ((colA & 7) << 1));
-                    const int offB = ((((colB >> 3) ^ (q4 << 2)) << 4) + ((colB & 7) << 1));
-                    s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ab + (kk * 16 + krow) * ROWB + offA));
-                    s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ab + (kk * 16 + krow + 4) * ROWB + offA));
-                    s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(bb + (kk * 16 + krow) * ROWB + offB));
-                    s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(bb + (kk * 16 + krow + 4) * ROWB + offB));
-                    typedef __attribute__((ext_vector_type(8))) short s16x8;
+                for (int i = 0; i < 4; ++i) {
+                    const char* ra = ab + s2 * 32 * ROWB + rowb;
+                    const char* rb = bb + s2 * 32 * ROWB + rowb;
+                    s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ra + (((chA + 2 * i) ^ key0) << 4)));
+                    s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ra + 4 * ROWB + (((chA + 2 * i) ^ key1) << 4)));
+                    s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(rb + (((chB + 2 * i) ^ key0) << 4)));
+                    s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(rb + 4 * ROWB + (((chB + 2 * i) ^ key1) << 4)));
                     s16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
                     s16x8 bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-                    af[i] = *reinterpret_cast<bf16x8*>(&av);
-                    bf[i] = *reinterpret_cast<bf16x8*>(&bv);
+                    af[s2][i] = *reinterpret_cast<bf16x8*>(&av);
+                    bf[s2][i] = *reinterpret_cast<bf16x8*>(&bv);
                 }
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);      // reads above, MFMA stream below
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s2][i], bf[s2][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         } else {
             const int fr = lane & 31, fh = lane >> 5;
 #pragma unroll 4
@@ -202,18 +213,35 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
     }
 
     // partial slab: ws[split][co][q]
-    const int fr = lane & 31, fh = lane >> 5;
     float* wsb = p.ws + (int64_t)split * p.Cout * p.Q;
+    if constexpr (FT16) {
+        const int l16 = lane & 15, kq = lane >> 4;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int q = q0 + wc * 64 + j * 32 + fr;
-        if (q >= p.Q) continue;
+        for (int j = 0; j < 4; ++j) {
+            const int q = q0 + wc * 64 + j * 16 + l16;
+            if (q >= p.Q) continue;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < 4; ++i) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                if (co < p.Cout) wsb[(int64_t)co * p.Q + q] = acc[i][j][r];
+                for (int r = 0; r < 4; ++r) {
+                    const int co = co0 + wr * 64 + i * 16 + 4 * kq + r;
+                    if (co < p.Cout) wsb[(int64_t)co * p.Q + q] = acc[i][j][r];
+                }
+            }
+        }
+    } else {
+        const int fr = lane & 31, fh = lane >> 5;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int q = q0 + wc * 64 + j * 32 + fr;
+            if (q >= p.Q) continue;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
+                    if (co < p.Cout) wsb[(int64_t)co * p.Q + q] = acc[i][j][r];
+                }
             }
         }
     }
