@@ -1,9 +1,11 @@
 // bf16 multi-head attention core on the matrix cores (v_mfma_f32_32x32x16_bf16), fused
 // QK^T -> softmax -> PV per (sample, head), plus the two backward kernels (dQ; dK+dV).
 //
-// One 256-thread workgroup (4 waves) per (b, head).  K and V of the head ([S][d], S <= 224 here)
-// are staged ONCE into LDS in their natural row-major layout (row stride 2*d32+16 bytes: an odd
-// number of 16-byte slots, so ds_read_b128 row fragments are conflict-free).  Each wave owns
+// One workgroup of up to 4 waves (one per 32-row tile, see attn_waves) per (b, head).  K and V of the head ([S][d], S <= 224 here)
+// are staged ONCE into LDS in their natural row-major layout (row stride 2*d+16 bytes: an odd
+// number of 16-byte slots, so ds_read_b128 row fragments are conflict-free; when d % 32 == 16 the
+// last 32-column transposed read of a row runs 16 columns into the pad and the next row - those
+// operand rows only feed output rows >= d, which are never stored; 32 bytes of slack end the image).  Each wave owns
 // 32-query tiles:
 //   S^T[key][q] = K . Q^T      MFMA A = K rows (ds_read_b128), B = Q^T (registers, straight from HBM)
 // so every lane holds ONE query column: the row softmax is an in-lane reduction over the 16
@@ -89,10 +91,10 @@ __device__ __forceinline__ bf16x8 tr_frag(const char* img, int stride, int row0,
 // forward
 // ------------------------------------------------------------------------------------------------
 template <int ND>
-__global__ __launch_bounds__(256) void attn_fwd_mfma(const AttnMP p) {
+__global__ __launch_bounds__(256, (ND <= 5 ? 2 : 1)) void attn_fwd_mfma(const AttnMP p) {
     constexpr int NDT = (ND + 1) / 2;
     constexpr int D32 = NDT * 32;
-    constexpr int STR = 2 * D32 + 16;
+    constexpr int STR = 2 * ND * 16 + 16;      // row = d values + one 16-byte slot (odd slot count: conflict-free row reads)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int Sp = (p.S + 31) & ~31;
     char* Ks = smem;
@@ -104,13 +106,13 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const AttnMP p) {
     const bf16_t* kg = p.k + (int64_t)b * p.S * p.ldk + hd * d;
     const bf16_t* vg = p.v + (int64_t)b * p.S * p.ldv + hd * d;
     bf16_t* og = p.out + (int64_t)b * p.L * p.ldo + hd * d;
-    stage_tile(Ks, kg, p.ldk, 0, Sp, p.S, d, D32, STR, tid, 256);
-    stage_tile(Vs, vg, p.ldv, 0, Sp, p.S, d, D32, STR, tid, 256);
+    stage_tile(Ks, kg, p.ldk, 0, Sp, p.S, d, d, STR, tid, (int)blockDim.x);
+    stage_tile(Vs, vg, p.ldv, 0, Sp, p.S, d, d, STR, tid, (int)blockDim.x);
     __syncthreads();
 
     const int fr = lane & 31, fh = lane >> 5;
     const int nkt = Sp >> 5;
-    for (int qt = wave; qt * 32 < p.L; qt += 4) {
+    for (int qt = wave; qt * 32 < p.L; qt += (int)(blockDim.x >> 6)) {
         const int l = qt * 32 + fr;
         const bool lok = l < p.L;
         bf16x8 qf[ND];
@@ -192,10 +194,10 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma(const AttnMP p) {
 // dQ: same query-on-lane structure
 // ------------------------------------------------------------------------------------------------
 template <int ND>
-__global__ __launch_bounds__(256) void attn_dq_mfma(const AttnMP p) {
+__global__ __launch_bounds__(256, (ND <= 5 ? 2 : 1)) void attn_dq_mfma(const AttnMP p) {
     constexpr int NDT = (ND + 1) / 2;
     constexpr int D32 = NDT * 32;
-    constexpr int STR = 2 * D32 + 16;
+    constexpr int STR = 2 * ND * 16 + 16;      // row = d values + one 16-byte slot (odd slot count: conflict-free row reads)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int Sp = (p.S + 31) & ~31;
     char* Ks = smem;
@@ -208,13 +210,13 @@ __global__ __launch_bounds__(256) void attn_dq_mfma(const AttnMP p) {
     const bf16_t* vg = p.v + (int64_t)b * p.S * p.ldv + hd * d;
     const bf16_t* gg = p.dout + (int64_t)b * p.L * p.lddo + hd * d;
     bf16_t* dqg = p.dq + (int64_t)b * p.L * p.lddq + hd * d;
-    stage_tile(Ks, kg, p.ldk, 0, Sp, p.S, d, D32, STR, tid, 256);
-    stage_tile(Vs, vg, p.ldv, 0, Sp, p.S, d, D32, STR, tid, 256);
+    stage_tile(Ks, kg, p.ldk, 0, Sp, p.S, d, d, STR, tid, (int)blockDim.x);
+    stage_tile(Vs, vg, p.ldv, 0, Sp, p.S, d, d, STR, tid, (int)blockDim.x);
     __syncthreads();
 
     const int fr = lane & 31, fh = lane >> 5;
     const int nkt = Sp >> 5;
-    for (int qt = wave; qt * 32 < p.L; qt += 4) {
+    for (int qt = wave; qt * 32 < p.L; qt += (int)(blockDim.x >> 6)) {
         const int l = qt * 32 + fr;
         const bool lok = l < p.L;
         bf16x8 qf[ND], gf[ND];
@@ -286,17 +288,17 @@ __global__ __launch_bounds__(256) void attn_dq_mfma(const AttnMP p) {
 // K/V tile (row reads for the B operands) into a private LDS region.
 // ------------------------------------------------------------------------------------------------
 template <int ND>
-__global__ __launch_bounds__(256) void attn_dkv_mfma(const AttnMP p) {
+__global__ __launch_bounds__(256, (ND <= 5 ? 2 : 1)) void attn_dkv_mfma(const AttnMP p) {
     constexpr int NDT = (ND + 1) / 2;
     constexpr int D32 = NDT * 32;
-    constexpr int STR = 2 * D32 + 16;
+    constexpr int STR = 2 * ND * 16 + 16;      // row = d values + one 16-byte slot (odd slot count: conflict-free row reads)
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool KV_REG = ND <= 5;                          // K/V B-operands straight from HBM into registers
     const int Lp = (p.L + 31) & ~31;
     char* Qs = smem;
     char* Gs = Qs + Lp * STR;
-    float* Ls = reinterpret_cast<float*>(Gs + Lp * STR);     // lse[Lp], delta[Lp]
-    float* Dl = Ls + Lp;
-    char* KVw = reinterpret_cast<char*>(Dl + Lp);            // per wave: K tile [32][STR] | V tile [32][STR]
+    char* KVw = Gs + Lp * STR + 32;                          // (ND > 5) per wave: K tile [32][STR] | V tile [32][STR]
+    // lse[l] / delta[l] live in the 16-byte pad slot of row l of the Q image (bytes 2d .. 2d+7)
     const int bh = blockIdx.x, b = bh / p.H, hd = bh - b * p.H;
     const int d = ND * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -306,11 +308,12 @@ __global__ __launch_bounds__(256) void attn_dkv_mfma(const AttnMP p) {
     const bf16_t* gg = p.dout + (int64_t)b * p.L * p.lddo + hd * d;
     bf16_t* dkg = p.dk + (int64_t)b * p.S * p.lddk + hd * d;
     bf16_t* dvg = p.dv + (int64_t)b * p.S * p.lddv + hd * d;
-    stage_tile(Qs, qg, p.ldq, 0, Lp, p.L, d, D32, STR, tid, 256);
-    stage_tile(Gs, gg, p.lddo, 0, Lp, p.L, d, D32, STR, tid, 256);
-    for (int i = tid; i < Lp; i += 256) {
-        Ls[i] = i < p.L ? p.lse[(int64_t)bh * p.L + i] : 0.f;
-        Dl[i] = i < p.L ? p.delta[(int64_t)bh * p.L + i] : 0.f;
+    stage_tile(Qs, qg, p.ldq, 0, Lp, p.L, d, d, STR, tid, (int)blockDim.x);
+    stage_tile(Gs, gg, p.lddo, 0, Lp, p.L, d, d, STR, tid, (int)blockDim.x);
+    for (int i = tid; i < Lp; i += (int)blockDim.x) {
+        float* pad = reinterpret_cast<float*>(Qs + i * STR + 2 * d);
+        pad[0] = i < p.L ? p.lse[(int64_t)bh * p.L + i] : 0.f;
+        pad[1] = i < p.L ? p.delta[(int64_t)bh * p.L + i] : 0.f;
     }
     __syncthreads();
 
@@ -319,14 +322,27 @@ __global__ __launch_bounds__(256) void attn_dkv_mfma(const AttnMP p) {
     const int nqt = Lp >> 5;
     char* Kw = KVw + wave * (2 * 32 * STR);
     char* Vw = Kw + 32 * STR;
-    for (int kt = wave; kt * 32 < Sp; kt += 4) {
-        // private K/V tile (only this wave touches Kw/Vw: wave-level ordering suffices)
-        stage_tile(Kw, kg, p.ldk, kt * 32, 32, p.S, d, D32, STR, lane, 64);
-        stage_tile(Vw, vg, p.ldv, kt * 32, 32, p.S, d, D32, STR, lane, 64);
-        __builtin_amdgcn_s_waitcnt(0);     // all counters: the wave's own LDS writes have landed
-        __builtin_amdgcn_wave_barrier();
+    for (int kt = wave; kt * 32 < Sp; kt += (int)(blockDim.x >> 6)) {
         const int key = kt * 32 + fr;
         const bool kok = key < p.S;
+        bf16x8 kreg[KV_REG ? ND : 1], vreg[KV_REG ? ND : 1];
+        if constexpr (KV_REG) {
+#pragma unroll
+            for (int ks = 0; ks < ND; ++ks) {
+                const int kr = kok ? key : 0;
+                uint4 a = *reinterpret_cast<const uint4*>(kg + (int64_t)kr * p.ldk + 16 * ks + 8 * fh);     // unconditional loads
+                uint4 c = *reinterpret_cast<const uint4*>(vg + (int64_t)kr * p.ldv + 16 * ks + 8 * fh);
+                if (!kok) { a = make_uint4(0, 0, 0, 0); c = make_uint4(0, 0, 0, 0); }
+                kreg[ks] = *reinterpret_cast<bf16x8*>(&a);
+                vreg[ks] = *reinterpret_cast<bf16x8*>(&c);
+            }
+        } else {
+            // private K/V tile (only this wave touches Kw/Vw: wave-level ordering suffices)
+            stage_tile(Kw, kg, p.ldk, kt * 32, 32, p.S, d, d, STR, lane, 64);
+            stage_tile(Vw, vg, p.ldv, kt * 32, 32, p.S, d, d, STR, lane, 64);
+            __builtin_amdgcn_s_waitcnt(0);     // all counters: the wave's own LDS writes have landed
+            __builtin_amdgcn_wave_barrier();
+        }
         f32x16 dk[NDT], dv[NDT];
 #pragma unroll
         for (int t = 0; t < NDT; ++t)
@@ -341,8 +357,12 @@ __global__ __launch_bounds__(256) void attn_dkv_mfma(const AttnMP p) {
                 const int co = (16 * ks + 8 * fh) * 2;
                 const bf16x8 qa = *reinterpret_cast<const bf16x8*>(Qs + (qt * 32 + fr) * STR + co);     // A: Q rows
                 const bf16x8 ga = *reinterpret_cast<const bf16x8*>(Gs + (qt * 32 + fr) * STR + co);     // A: dO rows
-                const bf16x8 kb = *reinterpret_cast<const bf16x8*>(Kw + fr * STR + co);                  // B: K^T (key on lane)
-                const bf16x8 vb = *reinterpret_cast<const bf16x8*>(Vw + fr * STR + co);                  // B: V^T
+                bf16x8 kb, vb;                                                                           // B: K^T, V^T (key on lane)
+                if constexpr (KV_REG) { kb = kreg[ks]; vb = vreg[ks]; }
+                else {
+                    kb = *reinterpret_cast<const bf16x8*>(Kw + fr * STR + co);
+                    vb = *reinterpret_cast<const bf16x8*>(Vw + fr * STR + co);
+                }
                 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kb, st, 0, 0, 0);    // S[q][key]
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, vb, dp, 0, 0, 0);    // dP[q][key]
             }
@@ -352,7 +372,8 @@ __global__ __launch_bounds__(256) void attn_dkv_mfma(const AttnMP p) {
                 const int l = qt * 32 + acc_row(r, fh);
                 float pv = 0.f, ds = 0.f;
                 if (kok && l < p.L) {
-                    const float pr = __expf(st[r] * p.scale - Ls[l]);
+                    const float2 ld2 = *reinterpret_cast<const float2*>(Qs + l * STR + 2 * d);      // (lse, delta) of query l
+                    const float pr = __expf(st[r] * p.scale - ld2.x);
                     float dpr = dp[r];
                     pv = pr;
                     if (p.drop_thresh) {
@@ -360,7 +381,7 @@ __global__ __launch_bounds__(256) void attn_dkv_mfma(const AttnMP p) {
                         pv = keep ? pr * p.drop_scale : 0.f;
                         dpr = keep ? dpr * p.drop_scale : 0.f;
                     }
-                    ds = pr * (dpr - Dl[l]) * p.scale;
+                    ds = pr * (dpr - ld2.y) * p.scale;
                 }
                 pd[r] = pv; st[r] = ds;
             }
@@ -396,11 +417,14 @@ __global__ __launch_bounds__(256) void attn_dkv_mfma(const AttnMP p) {
 }
 
 static inline int nd_supported(int d) { return d == 16 || d == 32 || d == 80 || d == 160; }
-static inline size_t str_bytes(int d) { return 2 * (size_t)(((d + 31) / 32) * 32) + 16; }
-static inline size_t fwd_lds_m(int S, int d) { return 2 * (size_t)((S + 31) & ~31) * str_bytes(d); }
-static inline size_t dkv_lds_m(int L, int d) {
+static inline size_t str_bytes(int d) { return 2 * (size_t)d + 16; }
+static inline size_t fwd_lds_m(int S, int d) { return 2 * (size_t)((S + 31) & ~31) * str_bytes(d) + 32; }
+// one wave per 32-row tile of the loop the waves share (queries for fwd/dQ, keys for dK/dV), at most 4: a 7x7 map
+// (49 rows) gets 2 waves per workgroup instead of 4 half-idle ones, and twice the workgroups fit a CU
+static inline int attn_waves(int rows) { const int t = (rows + 31) / 32; return t < 1 ? 1 : (t > 4 ? 4 : t); }
+static inline size_t dkv_lds_m(int L, int S, int d) {
     const size_t Lp = (L + 31) & ~31;
-    return 2 * Lp * str_bytes(d) + 2 * Lp * sizeof(float) + 4 * 2 * 32 * str_bytes(d);
+    return 2 * Lp * str_bytes(d) + 32 + (d > 80 ? (size_t)attn_waves(S) * 2 * 32 * str_bytes(d) + 32 : 0);
 }
 constexpr size_t MFMA_LDS_CAP = 158 * 1024;
 
@@ -408,7 +432,7 @@ constexpr size_t MFMA_LDS_CAP = 158 * 1024;
 int attn_mfma_applicable(int L, int S, int d, int dtype, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo) {
     if (dtype != PSG_BF16 || !nd_supported(d)) return 0;
     if (((ldq | ldk | ldv | ldo) & 7) != 0) return 0;                    // 16-byte row fragments
-    if (fwd_lds_m(S, d) > MFMA_LDS_CAP || dkv_lds_m(L, d) > MFMA_LDS_CAP) return 0;
+    if (fwd_lds_m(S, d) > MFMA_LDS_CAP || dkv_lds_m(L, S, d) > MFMA_LDS_CAP) return 0;
     return 1;
 }
 
@@ -431,15 +455,15 @@ int attn_mfma_init_attrs() {
 
 int attn_mfma_fwd(const AttnMP& p, hipStream_t s) {
     const int d = p.d;
-    ND_DISPATCH(attn_fwd_mfma, dim3(p.B * p.H), dim3(256), fwd_lds_m(p.S, d), s, p);
+    ND_DISPATCH(attn_fwd_mfma, dim3(p.B * p.H), dim3(64 * attn_waves(p.L)), fwd_lds_m(p.S, d), s, p);
     PSG_LAUNCH_CHECK("attn_fwd_mfma");
     return PSG_OK;
 }
 int attn_mfma_bwd(const AttnMP& p, hipStream_t s) {
     const int d = p.d;
-    ND_DISPATCH(attn_dq_mfma, dim3(p.B * p.H), dim3(256), fwd_lds_m(p.S, d), s, p);
+    ND_DISPATCH(attn_dq_mfma, dim3(p.B * p.H), dim3(64 * attn_waves(p.L)), fwd_lds_m(p.S, d), s, p);
     PSG_LAUNCH_CHECK("attn_dq_mfma");
-    ND_DISPATCH(attn_dkv_mfma, dim3(p.B * p.H), dim3(256), dkv_lds_m(p.L, d), s, p);
+    ND_DISPATCH(attn_dkv_mfma, dim3(p.B * p.H), dim3(64 * attn_waves(p.S)), dkv_lds_m(p.L, p.S, d), s, p);
     PSG_LAUNCH_CHECK("attn_dkv_mfma");
     return PSG_OK;
 }
