@@ -180,11 +180,13 @@ typedef struct psg_wgrad_desc {
     int32_t B, Hi, Wi, Cin, Ho, Wo, Cout, ksize, stride, pad;
     int32_t accumulate;
     int32_t dw_layout;  /* psg_w_layout of dw */
-    int32_t reserved0;
+    int32_t accumulate_bias;   /* like accumulate, for dbias */
     int64_t ldx, lddy;
     const void* x;    /* forward input  [B,Hi,Wi,Cin] */
     const void* dy;   /* output grad    [B,Ho,Wo,Cout] */
     float* dw;        /* Cout*Cin*k*k fp32 in dw_layout order */
+    float* dbias;     /* optional [Cout] fp32: the layer's bias gradient sum_m dy[m,co], produced by the SAME launch
+                         (the dY tiles are already in LDS: one extra MFMA against a ones operand per tile row) */
     void* ws;
     int64_t ws_bytes;
 } psg_wgrad_desc;

@@ -19,6 +19,7 @@ namespace psg {
 
 struct WgP {
     const void* x; const void* dy; float* ws;
+    float* bws;                                    // bias-gradient partials [splits][Cout] (or dbias itself), NULL = none
     int64_t ldx, lddy;
     int B, Hi, Wi, Cin, Ho, Wo, Cout, ks, stride, pad;
     int M, Q, taps;
@@ -147,6 +148,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
         for (int j = 0; j < NA; ++j)
 #pragma unroll
             for (int e = 0; e < AE; ++e) acc[i][j][e] = 0.f;
+    // bias gradient = column sums of the dY tile: the waves of tile column 0 multiply their dY fragments with a
+    // ones operand (every accumulator column then holds sum_k dY[k][co]); wave-uniform condition
+    const bool do_bias = p.bws != nullptr && qt == 0 && wc == 0;
+    AccT accb[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i)
+#pragma unroll
+        for (int e = 0; e < AE; ++e) accb[i][e] = 0.f;
 
     if (nsteps > 0) load_tiles(0);
     wait_vmcnt<0>();
@@ -191,6 +200,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s2][i], bf[s2][j], acc[i][j], 0, 0, 0);
+            if (do_bias) {
+                const bf16_t one = (bf16_t)1.0f;
+                const bf16x8 ones = {one, one, one, one, one, one, one, one};
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s2][i], ones, accb[i], 0, 0, 0);
+            }
             __builtin_amdgcn_sched_barrier(0);
         } else {
             const int fr = lane & 31, fh = lane >> 5;
@@ -206,6 +223,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                if (do_bias) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) accb[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], 1.0f, accb[i], 0, 0, 0);
+                }
             }
         }
         wait_vmcnt<0>();                   // AFTER the MFMA phase: the DMA of the next tile overlapped it
@@ -214,6 +235,30 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
 
     // partial slab: ws[split][co][q]
     float* wsb = p.ws + (int64_t)split * p.Cout * p.Q;
+    if (do_bias) {                                 // column 0 of the ones-product holds the sums
+        float* bw = p.bws + (int64_t)split * p.Cout;
+        if constexpr (FT16) {
+            if ((lane & 15) == 0) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int co = co0 + wr * 64 + i * 16 + 4 * (lane >> 4) + r;
+                        if (co < p.Cout) bw[co] = accb[i][r];
+                    }
+            }
+        } else {
+            if ((lane & 31) == 0) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int co = co0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        if (co < p.Cout) bw[co] = accb[i][r];
+                    }
+            }
+        }
+    }
     if constexpr (FT16) {
         const int l16 = lane & 15, kq = lane >> 4;
 #pragma unroll
@@ -273,8 +318,25 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
     }
 }
 
-// native order (dw[co][q], q = tap*Cin + ci): dw (+)= sum_s ws[s], float4, fixed order
-__global__ void wgrad_sum_kernel(const float* __restrict__ ws, float* __restrict__ dw, int64_t n4, int splits, int accumulate) {
+// dbias[co] (+)= sum_s bws[s][co], fixed order
+__device__ __forceinline__ void bias_sum(const float* __restrict__ bws, float* __restrict__ dbias, int Cout, int splits, int accumulate) {
+    const int co = blockIdx.x * blockDim.x + threadIdx.x;
+    if (co < Cout) {
+        float a = 0.f;
+        for (int s = 0; s < splits; ++s) a += bws[(int64_t)s * Cout + co];
+        if (accumulate) a += dbias[co];
+        dbias[co] = a;
+    }
+}
+__global__ void wgrad_bias_sum_kernel(const float* __restrict__ bws, float* __restrict__ dbias, int Cout, int splits, int accumulate) {
+    bias_sum(bws, dbias, Cout, splits, accumulate);
+}
+
+// native order (dw[co][q], q = tap*Cin + ci): dw (+)= sum_s ws[s], float4, fixed order; the first workgroups also
+// finish the bias gradient when bws != NULL
+__global__ void wgrad_sum_kernel(const float* __restrict__ ws, float* __restrict__ dw, int64_t n4, int splits, int accumulate,
+                                 const float* __restrict__ bws, float* __restrict__ dbias, int Cout, int accumulate_bias) {
+    if (bws) bias_sum(bws, dbias, Cout, splits, accumulate_bias);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         f32x4 a = reinterpret_cast<const f32x4*>(ws)[i];
         for (int s = 1; s < splits; ++s) a += reinterpret_cast<const f32x4*>(ws)[i + (int64_t)s * n4];
@@ -352,7 +414,9 @@ int64_t psg_conv_wgrad_workspace_bytes(const psg_wgrad_desc* d) {
     if (wgrad_check(d) != PSG_OK) return -1;
     WgP p;
     wgrad_plan(d, p);
-    return wgrad_direct(d, p) ? 0 : (int64_t)p.splits * d->Cout * p.Q * sizeof(float);
+    const int64_t slabs = wgrad_direct(d, p) ? 0 : (int64_t)p.splits * d->Cout * p.Q;
+    const int64_t bias = (d->dbias && !(p.splits == 1 && !d->accumulate_bias)) ? (int64_t)p.splits * d->Cout : 0;
+    return (slabs + bias) * (int64_t)sizeof(float);
 }
 
 int psg_conv_wgrad(const psg_wgrad_desc* d, psg_stream_t stream) {
@@ -364,11 +428,15 @@ int psg_conv_wgrad(const psg_wgrad_desc* d, psg_stream_t stream) {
     wgrad_plan(d, p);
     const bool direct = wgrad_direct(d, p);
     const bool native = d->dw_layout == PSG_W_OHWI || p.taps == 1;
-    if (!direct) {
+    const bool bias_direct = d->dbias && p.splits == 1 && !d->accumulate_bias;
+    const int64_t slab_floats = direct ? 0 : (int64_t)p.splits * d->Cout * p.Q;
+    const int64_t bias_floats = (d->dbias && !bias_direct) ? (int64_t)p.splits * d->Cout : 0;
+    if (slab_floats + bias_floats > 0) {
         PSG_REQUIRE(d->ws && aligned16(d->ws), PSG_ERR_ARG, "wgrad: workspace missing or not 16-byte aligned");
-        PSG_REQUIRE(d->ws_bytes >= (int64_t)p.splits * d->Cout * p.Q * (int64_t)sizeof(float), PSG_ERR_WORKSPACE, "wgrad: workspace too small");
+        PSG_REQUIRE(d->ws_bytes >= (slab_floats + bias_floats) * (int64_t)sizeof(float), PSG_ERR_WORKSPACE, "wgrad: workspace too small");
     }
     p.x = d->x; p.dy = d->dy; p.ws = direct ? d->dw : (float*)d->ws; p.ldx = d->ldx; p.lddy = d->lddy;
+    p.bws = !d->dbias ? nullptr : (bias_direct ? d->dbias : (float*)d->ws + slab_floats);
     p.B = d->B; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
     p.ks = d->ksize; p.stride = d->stride; p.pad = d->pad;
     p.inv_HoWo = 1.0f / (float)(d->Ho * d->Wo); p.inv_Wo = 1.0f / (float)d->Wo;
@@ -387,11 +455,18 @@ int psg_conv_wgrad(const psg_wgrad_desc* d, psg_stream_t stream) {
         else hipLaunchKernelGGL(wgrad_kernel<float>, dim3(grid), dim3(256), 4 * 32 * 512, s, p);
     }
     PSG_LAUNCH_CHECK("wgrad");
+    const bool bias_pending = d->dbias && !bias_direct;
+    if (bias_pending && (direct || !native)) {
+        hipLaunchKernelGGL(wgrad_bias_sum_kernel, dim3((d->Cout + 255) / 256), dim3(256), 0, s, p.bws, d->dbias, d->Cout, p.splits, d->accumulate_bias);
+        PSG_LAUNCH_CHECK("wgrad_bias_sum");
+    }
     if (direct) return PSG_OK;
     if (native) {                                  // Cout*Q is a multiple of 16 (Cin, Cout multiples of 4)
         const int64_t n4 = (int64_t)d->Cout * p.Q / 4;
-        const int g = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
-        hipLaunchKernelGGL(wgrad_sum_kernel, dim3(g), dim3(256), 0, s, (const float*)d->ws, d->dw, n4, p.splits, d->accumulate);
+        int g = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+        if (g < (d->Cout + 255) / 256) g = (d->Cout + 255) / 256;       // enough workgroups to cover the bias channels
+        hipLaunchKernelGGL(wgrad_sum_kernel, dim3(g), dim3(256), 0, s, (const float*)d->ws, d->dw, n4, p.splits, d->accumulate,
+                           bias_pending ? p.bws : nullptr, d->dbias, d->Cout, d->accumulate_bias);
     } else {
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(d->Cout, (d->Cin + 255) / 256), dim3(256), 0, s, (const float*)d->ws, d->dw,
                            d->Cout, d->Cin, p.taps, p.splits, d->accumulate);

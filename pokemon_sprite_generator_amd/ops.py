@@ -165,7 +165,8 @@ def _conv_launch(lib, dtype, x, ldx, w, ldw, y, ldy, geom, Cin, Cout, transposed
     check(lib.psg_conv_fwd(C.byref(d), stream_ptr()), "psg_conv_fwd")
 
 
-def _wgrad_launch(lib, dtype, x, ldx, dy, lddy, dw, geom, Cin, Cout, accumulate=False):
+def _wgrad_launch(lib, dtype, x, ldx, dy, lddy, dw, geom, Cin, Cout, accumulate=False, dbias=None, accumulate_bias=False):
+    """dw (+)= dy^T . gather(x); with `dbias` the same launch also produces the bias gradient (column sums of dy)."""
     B, Hi, Wi, Ho, Wo, ks, stride, pad = geom
     d = WgradDesc()
     d.dtype = dtype_code(dtype)
@@ -180,6 +181,10 @@ def _wgrad_launch(lib, dtype, x, ldx, dy, lddy, dw, geom, Cin, Cout, accumulate=
             out.copy_(dw)
     d.dw_layout = layout
     d.x, d.dy, d.dw = x.data_ptr(), dy.data_ptr(), out.data_ptr()
+    if dbias is not None:
+        if dbias.dtype != torch.float32 or not dbias.is_contiguous() or dbias.numel() != Cout:
+            raise _lib.PsgError("wgrad: dbias must be a contiguous fp32 [Cout] tensor")
+        d.dbias, d.accumulate_bias = dbias.data_ptr(), int(accumulate_bias)
     need = lib.psg_conv_wgrad_workspace_bytes(C.byref(d))
     if need < 0:
         check(-1, "psg_conv_wgrad_workspace_bytes")
@@ -198,6 +203,22 @@ def _colsum(lib, a, lda, R, groups, cols, dtype, out_dtype, keep2d=False, out=No
     ws = _lib.workspace(need, a.device)
     check(lib.psg_colsum(ptr(a), lda, ptr(out), cols, R, groups, cols, dtype_code(dtype), dtype_code(out_dtype), int(accumulate),
                          ptr(ws), ws.numel(), stream_ptr()), "psg_colsum")
+    return out
+
+
+def _param_out(param):
+    """(out, accumulate, sink entry or None) for a parameter gradient: the registered sink view or a fresh tensor."""
+    e = GradSink.get(param)
+    if e is not None:
+        return e.view, e.written, e
+    return torch.empty_like(param), False, None
+
+
+def _param_ret(out, e):
+    """What autograd gets back for a gradient produced into `_param_out`'s tensor."""
+    if e is not None:
+        GradSink.done(e)
+        return None
     return out
 
 
@@ -281,9 +302,16 @@ class _ConvFn(torch.autograd.Function):
             dx = torch.empty(x_shape, dtype=dtype, device=dy.device)
             tgeom = (B, Ho, Wo, Hi, Wi, ks, stride, pad)     # gather source = dY grid, result = input grid
             _conv_launch(lib, dtype, g, ldg, wd, 0, dx, Cin, tgeom, Cout, Cin, transposed=True)
+        want_b = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw = _param_grad(ctx.weight_param, lambda out, acc: _wgrad_launch(lib, dtype, xr, ldx, g, ldg, out, geom, Cin, Cout, accumulate=acc))
-        if has_bias and ctx.needs_input_grad[2]:
+            # one launch: weight gradient + (fused) bias gradient, straight into the gradient arena when registered
+            wo, wacc, we = _param_out(ctx.weight_param)
+            bo, bacc, be = _param_out(ctx.bias_param) if want_b else (None, False, None)
+            _wgrad_launch(lib, dtype, xr, ldx, g, ldg, wo, geom, Cin, Cout, accumulate=wacc, dbias=bo, accumulate_bias=bacc)
+            dw = _param_ret(wo, we)
+            if want_b:
+                db = _param_ret(bo, be)
+        elif want_b:
             db = _param_grad(ctx.bias_param, lambda out, acc: _colsum(lib, g, ldg, M, 1, Cout, dtype, torch.float32, out=out, accumulate=acc))
         if has_ra and ctx.needs_input_grad[3]:
             dra = _colsum(lib, g, ldg, Ho * Wo, B, Cout, dtype, dtype, keep2d=True)
@@ -344,11 +372,16 @@ class _CrossInProjFn(torch.autograd.Function):
             dtp = torch.empty(ts, dtype=dtype, device=dq.device)
             _conv_launch(lib, dtype, dkr, lddk, wd.data_ptr() + E * esz, kpd, dtp, E, (Mk, 1, 1, 1, 1, 1, 1, 0), 2 * E, E, transposed=True)
         if ctx.needs_input_grad[2]:
-            def wg(out, acc):
-                _wgrad_launch(lib, dtype, xr, ldx, dqr, lddq, out[:E], (Mq, 1, 1, 1, 1, 1, 1, 0), E, E, accumulate=acc)
-                _wgrad_launch(lib, dtype, tr, ldt, dkr, lddk, out[E:], (Mk, 1, 1, 1, 1, 1, 1, 0), E, 2 * E, accumulate=acc)
-            dw = _param_grad(ctx.weight_param, wg)
-        if ctx.needs_input_grad[3]:
+            wo, wacc, we = _param_out(ctx.weight_param)
+            bo, bacc, be = _param_out(ctx.bias_param) if ctx.needs_input_grad[3] else (None, False, None)
+            _wgrad_launch(lib, dtype, xr, ldx, dqr, lddq, wo[:E], (Mq, 1, 1, 1, 1, 1, 1, 0), E, E, accumulate=wacc,
+                          dbias=None if bo is None else bo[:E], accumulate_bias=bacc)
+            _wgrad_launch(lib, dtype, tr, ldt, dkr, lddk, wo[E:], (Mk, 1, 1, 1, 1, 1, 1, 0), E, 2 * E, accumulate=wacc,
+                          dbias=None if bo is None else bo[E:], accumulate_bias=bacc)
+            dw = _param_ret(wo, we)
+            if bo is not None:
+                db = _param_ret(bo, be)
+        elif ctx.needs_input_grad[3]:
             def bg(out, acc):
                 _colsum(lib, dqr, lddq, Mq, 1, E, dtype, torch.float32, out=out[:E], accumulate=acc)
                 _colsum(lib, dkr, lddk, Mk, 1, 2 * E, dtype, torch.float32, out=out[E:], accumulate=acc)
