@@ -32,6 +32,10 @@ struct ConvP {
     int act; float alpha;
     uint32_t drop_thresh; float drop_scale; uint64_t drop_seed;
     uint32_t x_bytes, w_bytes;     // extents for the bounds-checked buffer loads
+    // MODE 3 (one parity class of a stride-2 data gradient): result pixels (sub_h0 + 2i, sub_w0 + 2j), i < sub_nH,
+    // j < sub_nW; only the ntap filter taps that reach them: source pixel (i + tap_dh, j + tap_dw), weight tap tap_wi
+    int sub_h0, sub_w0, sub_nH, sub_nW, ntap;
+    int tap_dh[4], tap_dw[4], tap_wi[4];
 };
 
 template <typename T> struct Mma;
@@ -64,7 +68,9 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {   // byte offset in
 
 // MODE 0: forward gather, K step inside one tap (Cin % K-step == 0)   [every 3x3 / 1x1 layer of the U-Net body]
 // MODE 1: data-gradient gather of a stride-1 conv, same fast decode
-// MODE 2: generic (stride-2 data gradient, Cin = 8 first/last convs): per-thread tap decode
+// MODE 2: generic (Cin = 8 first/last convs, odd channel counts): per-thread tap decode
+// MODE 3: stride-2 data gradient, one launch per output-pixel parity class: on the class's own (i, j) grid the
+//         gather is a stride-1 gather with 1, 2 or 4 taps (table in ConvP) instead of 9 taps of which 3/4 miss
 // NT threads (256: 4 waves as 2m x 2n; 512: 8 waves as 4m x 2n), NSTAGE LDS tile buffers:
 //   NSTAGE 2: the tile of step kt+1 is requested at the top of step kt (plain __syncthreads, drains vmcnt)
 //   NSTAGE 3: the tile of step kt+2 is requested at the top of step kt and stays in flight ACROSS the barrier
@@ -125,7 +131,15 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(const ConvP p) {
 #pragma unroll
         for (int j = 0; j < JX; ++j) {
             const int m = m0 + sr + RPP * j;
-            if (m < p.M) {
+            if (MODE == 3) {
+                if (m < p.M) {
+                    const int hw = p.sub_nH * p.sub_nW;
+                    const int b = m / hw, rm = m - b * hw;
+                    const int i = rm / p.sub_nW, jj = rm - i * p.sub_nW;
+                    x_hb[j] = i; x_wb[j] = jj;
+                    x_base[j] = ((b * p.Hi + i) * p.Wi + jj) * (int)p.ldx * ESZ + sc * 16;
+                } else { x_hb[j] = -100000; x_wb[j] = -100000; x_base[j] = 0; }
+            } else if (m < p.M) {
                 const int b = m / HoWo, rm = m - b * HoWo;
                 const int ho = rm / p.Wo, wo = rm - ho * p.Wo;
                 if (p.transposed) { x_hb[j] = ho + p.pad; x_wb[j] = wo + p.pad; }
@@ -142,13 +156,27 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(const ConvP p) {
     typedef __attribute__((address_space(3))) char* lds_ptr_t;
     const uint32_t lds_wave = (uint32_t)(size_t)(lds_ptr_t)smem + (uint32_t)__builtin_amdgcn_readfirstlane(wave) * 1024u;
     auto load_tiles = [&](int kt, int buf) {          // issue the LDS-DMA of K step kt into LDS buffer buf
-        const uint32_t kbytes = (uint32_t)kt * 128u;          // 8 chunks of 16 B per K step
+        // weight K offset: 8 chunks of 16 B per K step; MODE 3 walks only its own taps of the 9-tap K axis
+        const uint32_t kbytes = MODE == 3 ? (uint32_t)(p.tap_wi[t_kh] * p.cpt + t_c0) * 16u : (uint32_t)kt * 128u;
         const uint32_t wdst = lds_wave + (uint32_t)buf * BUF_BYTES;
         const uint32_t xdst = wdst + BN * 128;
 #pragma unroll
         for (int j = 0; j < JW; ++j)
             lds_dma16(wrs, wdst + j * PASS_BYTES, w_off[j] + kbytes);
-        if (MODE != 2) {
+        if (MODE == 3) {                                   // t_kh is the index into the class's tap table
+            const int dh = p.tap_dh[t_kh], dw = p.tap_dw[t_kh];
+            const int delta = ((dh * p.Wi + dw) * (int)p.ldx + t_c0 * CH) * ESZ;                 // wave-uniform
+#pragma unroll
+            for (int j = 0; j < JX; ++j) {
+                const int sh = x_hb[j] + dh, sw = x_wb[j] + dw;
+                const bool ok = (unsigned)sh < (unsigned)p.Hi && (unsigned)sw < (unsigned)p.Wi;
+                uint32_t off = (uint32_t)(x_base[j] + delta);
+                off = ok ? off : OOB;
+                lds_dma16(xrs, xdst + j * PASS_BYTES, off);
+            }
+            t_c0 += 8;
+            if (t_c0 >= p.cpt) { t_c0 = 0; ++t_kh; }
+        } else if (MODE != 2) {
             const int sgn = MODE == 0 ? 1 : -1;
             const int delta = (sgn * (t_kh * p.Wi + t_kw) * (int)p.ldx + t_c0 * CH) * ESZ;      // wave-uniform
 #pragma unroll
@@ -302,7 +330,17 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(const ConvP p) {
     T* preg = reinterpret_cast<T*>(p.preact);
     const T* dug = reinterpret_cast<const T*>(p.dact_u);
     const int HoWo = p.Ho * p.Wo;
-    auto emit = [&](int m, int b, int n, f32x4 v) {       // 4 consecutive output channels n..n+3 of pixel m
+    auto out_row = [&](int m, int& b) {                   // tile pixel m -> row of y (and its sample index)
+        if (MODE == 3) {
+            const int hw = p.sub_nH * p.sub_nW;
+            b = m / hw;
+            const int rm = m - b * hw, i = rm / p.sub_nW, jj = rm - i * p.sub_nW;
+            return (b * p.Ho + p.sub_h0 + 2 * i) * p.Wo + p.sub_w0 + 2 * jj;
+        }
+        b = m / HoWo;
+        return m;
+    };
+    auto emit = [&](int m, int b, int n, f32x4 v) {       // 4 consecutive output channels n..n+3 of y row m
         if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
         if (rag) v += load4<T>(rag + (int64_t)b * p.ldra + n);
         if (preg) store4<T>(preg + (int64_t)m * p.ldpre + n, v);
@@ -326,9 +364,10 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(const ConvP p) {
     if constexpr (FT16) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const int m = m0 + wm * (TM * 32) + j * 16 + l16;
-            if (m >= p.M) continue;
-            const int b = m / HoWo;
+            const int mt_ = m0 + wm * (TM * 32) + j * 16 + l16;
+            if (mt_ >= p.M) continue;
+            int b;
+            const int m = out_row(mt_, b);
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const int n = n0 + wn * (TN * 32) + i * 16 + 4 * kq;
@@ -340,9 +379,10 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(const ConvP p) {
     } else {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const int m = m0 + wm * (TM * 32) + j * 32 + fr;
-            if (m >= p.M) continue;
-            const int b = m / HoWo;
+            const int mt_ = m0 + wm * (TM * 32) + j * 32 + fr;
+            if (mt_ >= p.M) continue;
+            int b;
+            const int m = out_row(mt_, b);
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
 #pragma unroll
@@ -366,8 +406,9 @@ static int launch_conv(const ConvP& p, hipStream_t stream) {
     q.ntiles = (p.N + BN - 1) / BN;
     const int grid = q.mtiles * q.ntiles;
     ProfScope prof(p.transposed ? PROF_CONV_DGRAD : PROF_CONV_FWD, 2.0 * (double)p.M * (double)p.N * (double)p.taps * (double)p.Cin, stream);
-    const int mode = !p.fast ? 2 : (!p.transposed ? 0 : (p.stride == 1 ? 1 : 2));
-    if (mode == 0) hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 0, NT, NSTAGE>), dim3(grid), dim3(NT), lds, stream, q);
+    const int mode = p.ntap > 0 ? 3 : (!p.fast ? 2 : (!p.transposed ? 0 : (p.stride == 1 ? 1 : 2)));
+    if (mode == 3) hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 3, NT, NSTAGE>), dim3(grid), dim3(NT), lds, stream, q);
+    else if (mode == 0) hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 0, NT, NSTAGE>), dim3(grid), dim3(NT), lds, stream, q);
     else if (mode == 1) hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 1, NT, NSTAGE>), dim3(grid), dim3(NT), lds, stream, q);
     else hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 2, NT, NSTAGE>), dim3(grid), dim3(NT), lds, stream, q);
     hipError_t e = hipGetLastError();
@@ -381,7 +422,44 @@ static int set_conv_attrs() {
     PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 0, NT, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 1, NT, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 2, NT, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 3, NT, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     return PSG_OK;
+}
+
+// tile choice: maximise (useful fraction of the tile grid) x (chip fill of the last wave) x (tile efficiency)
+static int choose_and_launch(const ConvP& p, int dtype, hipStream_t s) {
+    const int64_t M = p.M;
+    int BM = 128, BN = 128;
+    {
+        static int force = -2;                             // PSG_CONV_TILE=0..3 pins a candidate (kernel A/B runs)
+        if (force == -2) { const char* e = getenv("PSG_CONV_TILE"); force = e ? atoi(e) : -1; }
+        const int cand[4][2] = {{256, 128}, {128, 128}, {128, 64}, {64, 64}};
+        const double eff[4] = {0.90, 1.0, 0.78, 0.55};     // measured relative MFMA efficiency of the tile shapes
+        const double slots_of[4] = {256.0, 512.0, 512.0, 512.0};   // resident workgroups on the chip
+        double best = -1.0;
+        for (int c = 0; c < 4; ++c) {
+            const double tiles = (double)((M + cand[c][0] - 1) / cand[c][0]) * (double)((p.N + cand[c][1] - 1) / cand[c][1]);
+            const double useful = (double)M * p.N / (tiles * cand[c][0] * cand[c][1]);
+            const double waves = ceil(tiles / slots_of[c]);
+            double score = useful * (tiles / (waves * slots_of[c])) * eff[c];
+            if (c == 0 && p.KT < 4) score = 0.0;           // the 3-stage ring needs a few K steps to pay off
+            if (force >= 0) score = (c == force) ? 1.0 : 0.0;
+            if (score > best) { best = score; BM = cand[c][0]; BN = cand[c][1]; }
+        }
+    }
+    if (BM == 256) {
+        if (dtype == PSG_F32) return launch_conv<float, 256, 128, 512, 3>(p, s);
+        return launch_conv<bf16_t, 256, 128, 512, 3>(p, s);
+    }
+    if (dtype == PSG_F32) {
+        if (BM == 128 && BN == 128) return launch_conv<float, 128, 128>(p, s);
+        if (BM == 128 && BN == 64) return launch_conv<float, 128, 64>(p, s);
+        return launch_conv<float, 64, 64>(p, s);
+    } else {
+        if (BM == 128 && BN == 128) return launch_conv<bf16_t, 128, 128>(p, s);
+        if (BM == 128 && BN == 64) return launch_conv<bf16_t, 128, 64>(p, s);
+        return launch_conv<bf16_t, 64, 64>(p, s);
+    }
 }
 
 }  // namespace psg
@@ -457,39 +535,35 @@ int psg_conv_fwd(const psg_conv_desc* d, psg_stream_t stream) {
         p.x_bytes = (uint32_t)xb; p.w_bytes = (uint32_t)wb;
     }
 
-    // tile choice: maximise (useful fraction of the tile grid) x (chip fill of the last wave) x (tile efficiency)
     hipStream_t s = (hipStream_t)stream;
-    int BM = 128, BN = 128;
-    {
-        static int force = -2;                             // PSG_CONV_TILE=0..3 pins a candidate (kernel A/B runs)
-        if (force == -2) { const char* e = getenv("PSG_CONV_TILE"); force = e ? atoi(e) : -1; }
-        const int cand[4][2] = {{256, 128}, {128, 128}, {128, 64}, {64, 64}};
-        const double eff[4] = {0.90, 1.0, 0.78, 0.55};     // measured relative MFMA efficiency of the tile shapes
-        const double slots_of[4] = {256.0, 512.0, 512.0, 512.0};   // resident workgroups on the chip
-        double best = -1.0;
-        for (int c = 0; c < 4; ++c) {
-            const double tiles = (double)((M + cand[c][0] - 1) / cand[c][0]) * (double)((d->Cout + cand[c][1] - 1) / cand[c][1]);
-            const double useful = (double)M * d->Cout / (tiles * cand[c][0] * cand[c][1]);
-            const double waves = ceil(tiles / slots_of[c]);
-            double score = useful * (tiles / (waves * slots_of[c])) * eff[c];
-            if (c == 0 && p.KT < 4) score = 0.0;           // the 3-stage ring needs a few K steps to pay off
-            if (force >= 0) score = (c == force) ? 1.0 : 0.0;
-            if (score > best) { best = score; BM = cand[c][0]; BN = cand[c][1]; }
-        }
+    p.ntap = 0; p.sub_h0 = p.sub_w0 = p.sub_nH = p.sub_nW = 0;
+    if (p.transposed && p.stride == 2 && p.fast && p.ks == 3) {
+        // Data gradient of a stride-2 conv: a result pixel (ho, wo) is reached only by the taps with
+        // kh = (ho + pad) mod 2 (mod 2), same for kw - 1, 2, 2 or 4 of the 9.  One launch per parity class, each a
+        // dense stride-1-like gather on the class's own grid: 2.25 taps per pixel on average instead of 9.
+        for (int ah = 0; ah < 2; ++ah)
+            for (int aw = 0; aw < 2; ++aw) {
+                ConvP q = p;
+                q.sub_h0 = (ah - p.pad) & 1; q.sub_w0 = (aw - p.pad) & 1;
+                q.sub_nH = (p.Ho - q.sub_h0 + 1) >> 1; q.sub_nW = (p.Wo - q.sub_w0 + 1) >> 1;
+                if (q.sub_nH <= 0 || q.sub_nW <= 0) continue;
+                q.ntap = 0;
+                for (int kh = ah; kh < 3; kh += 2)
+                    for (int kw = aw; kw < 3; kw += 2) {
+                        q.tap_dh[q.ntap] = (q.sub_h0 + p.pad - kh) / 2;
+                        q.tap_dw[q.ntap] = (q.sub_w0 + p.pad - kw) / 2;
+                        q.tap_wi[q.ntap] = kh * 3 + kw;
+                        ++q.ntap;
+                    }
+                q.M = p.B * q.sub_nH * q.sub_nW;
+                q.taps = q.ntap;                           // (profiling: useful FLOPs of this class)
+                q.KT = q.ntap * p.tpt;
+                const int rc = choose_and_launch(q, d->dtype, s);
+                if (rc) return rc;
+            }
+        return PSG_OK;
     }
-    if (BM == 256) {
-        if (d->dtype == PSG_F32) return launch_conv<float, 256, 128, 512, 3>(p, s);
-        return launch_conv<bf16_t, 256, 128, 512, 3>(p, s);
-    }
-    if (d->dtype == PSG_F32) {
-        if (BM == 128 && BN == 128) return launch_conv<float, 128, 128>(p, s);
-        if (BM == 128 && BN == 64) return launch_conv<float, 128, 64>(p, s);
-        return launch_conv<float, 64, 64>(p, s);
-    } else {
-        if (BM == 128 && BN == 128) return launch_conv<bf16_t, 128, 128>(p, s);
-        if (BM == 128 && BN == 64) return launch_conv<bf16_t, 128, 64>(p, s);
-        return launch_conv<bf16_t, 64, 64>(p, s);
-    }
+    return choose_and_launch(p, d->dtype, s);
 }
 
 }  // extern "C"
