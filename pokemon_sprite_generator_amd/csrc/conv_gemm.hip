@@ -80,7 +80,7 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(const ConvP p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // the LDS-DMA builtin exists only in the device pass
     constexpr int CH = Elem<T>::CH;
     constexpr int WAVES_M = NT / 128;           // waves along m (2 along n)
-    constexpr int TM = BM / (32 * WAVES_M), TN = BN / 64;   // 32x32 MFMA tiles per wave along m / n
+    constexpr int WM = BM / WAVES_M, WN = BN / 2;           // pixels / channels per wave (BN = 160 -> 80 = 5 x 16: bf16 only)
     constexpr int RPP = NT / 8;                 // rows per staging pass (8 lanes x 16 B per 128-byte row)
     constexpr int JX = BM / RPP, JW = BN / RPP; // staging passes
     constexpr int PASS_BYTES = RPP * 128;
@@ -214,7 +214,9 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(const ConvP p) {
     };
 
     constexpr bool FT16 = sizeof(T) == 2;                 // bf16: 16x16x32 tiles; fp32: 32x32x2 tiles
-    constexpr int NA = FT16 ? TN * 2 : TN, NB = FT16 ? TM * 2 : TM;   // fragment tiles per wave along n / m
+    constexpr int FT = FT16 ? 16 : 32;
+    static_assert(WN % FT == 0 && WM % FT == 0, "wave tile must be a whole number of MFMA tiles");
+    constexpr int NA = WN / FT, NB = WM / FT;             // fragment tiles per wave along n / m
     constexpr int AE = FT16 ? 4 : 16;
     typedef float AccT __attribute__((ext_vector_type(AE)));
     AccT acc[NA][NB];
@@ -229,7 +231,8 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(const ConvP p) {
     const int l16 = lane & 15, kq = lane >> 4;            // 16x16x32 fragment coordinates (bf16 path)
     // fragment row bases (bytes) and chunk swizzle key; tile rows step by 16 / 32, which leaves (row>>1)&7 unchanged
     const int frow = FT16 ? l16 : fr;
-    const int rd_w = (wn * (TN * 32) + frow) * 128, rd_x = BN * 128 + (wm * (TM * 32) + frow) * 128;
+    static_assert((WN / 2) % 8 == 0 && (WM / 2) % 8 == 0, "wave row bases must keep the (row>>1)&7 swizzle key");
+    const int rd_w = (wn * WN + frow) * 128, rd_x = BN * 128 + (wm * WM + frow) * 128;
     const int swz = (frow >> 1) & 7;
     constexpr int FSTEP = (FT16 ? 16 : 32) * 128;         // byte step between fragment tiles
 
@@ -364,13 +367,13 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(const ConvP p) {
     if constexpr (FT16) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const int mt_ = m0 + wm * (TM * 32) + j * 16 + l16;
+            const int mt_ = m0 + wm * WM + j * 16 + l16;
             if (mt_ >= p.M) continue;
             int b;
             const int m = out_row(mt_, b);
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                const int n = n0 + wn * (TN * 32) + i * 16 + 4 * kq;
+                const int n = n0 + wn * WN + i * 16 + 4 * kq;
                 if (n >= p.N) continue;
                 f32x4 v = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                 emit(m, b, n, v);
@@ -379,7 +382,7 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(const ConvP p) {
     } else {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
-            const int mt_ = m0 + wm * (TM * 32) + j * 32 + fr;
+            const int mt_ = m0 + wm * WM + j * 32 + fr;
             if (mt_ >= p.M) continue;
             int b;
             const int m = out_row(mt_, b);
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(const ConvP p) {
             for (int i = 0; i < NA; ++i) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const int n = n0 + wn * (TN * 32) + i * 32 + 8 * g + 4 * fh;
+                    const int n = n0 + wn * WN + i * 32 + 8 * g + 4 * fh;
                     if (n >= p.N) continue;
                     f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                     emit(m, b, n, v);
@@ -433,11 +436,13 @@ static int choose_and_launch(const ConvP& p, int dtype, hipStream_t s) {
     {
         static int force = -2;                             // PSG_CONV_TILE=0..3 pins a candidate (kernel A/B runs)
         if (force == -2) { const char* e = getenv("PSG_CONV_TILE"); force = e ? atoi(e) : -1; }
-        const int cand[4][2] = {{256, 128}, {128, 128}, {128, 64}, {64, 64}};
-        const double eff[4] = {0.90, 1.0, 0.78, 0.55};     // measured relative MFMA efficiency of the tile shapes
-        const double slots_of[4] = {256.0, 512.0, 512.0, 512.0};   // resident workgroups on the chip
+        const int cand[5][2] = {{256, 128}, {128, 128}, {128, 64}, {64, 64}, {128, 160}};
+        double eff[5] = {0.90, 1.0, 0.78, 0.55, 1.0};      // measured relative MFMA efficiency of the tile shapes
+        if (p.KT <= 10) eff[2] = 1.1;                      // K <= 640: 3 resident 128x64 workgroups hide the short K loop's ends
+        if (dtype != PSG_BF16) eff[4] = 0.0;               // 160 = 2 x 5 x 16: only the 16x16x32 bf16 tiles divide it
+        const double slots_of[5] = {256.0, 512.0, 512.0, 512.0, 512.0};   // resident workgroups on the chip
         double best = -1.0;
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < 5; ++c) {
             const double tiles = (double)((M + cand[c][0] - 1) / cand[c][0]) * (double)((p.N + cand[c][1] - 1) / cand[c][1]);
             const double useful = (double)M * p.N / (tiles * cand[c][0] * cand[c][1]);
             const double waves = ceil(tiles / slots_of[c]);
@@ -451,6 +456,7 @@ static int choose_and_launch(const ConvP& p, int dtype, hipStream_t s) {
         if (dtype == PSG_F32) return launch_conv<float, 256, 128, 512, 3>(p, s);
         return launch_conv<bf16_t, 256, 128, 512, 3>(p, s);
     }
+    if (BN == 160) return launch_conv<bf16_t, 128, 160>(p, s);
     if (dtype == PSG_F32) {
         if (BM == 128 && BN == 128) return launch_conv<float, 128, 128>(p, s);
         if (BM == 128 && BN == 64) return launch_conv<float, 128, 64>(p, s);
@@ -475,6 +481,7 @@ int psg_conv_init_attrs(void) {
     if ((rc = set_conv_attrs<bf16_t, 128, 64>())) return rc;
     if ((rc = set_conv_attrs<float, 64, 64>())) return rc;
     if ((rc = set_conv_attrs<bf16_t, 64, 64>())) return rc;
+    if ((rc = set_conv_attrs<bf16_t, 128, 160>())) return rc;
     if ((rc = set_conv_attrs<float, 256, 128, 512, 3>())) return rc;
     if ((rc = set_conv_attrs<bf16_t, 256, 128, 512, 3>())) return rc;
     return PSG_OK;
