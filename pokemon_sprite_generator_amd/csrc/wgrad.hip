@@ -97,6 +97,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
     const int od_A0 = od_dW * SW + od_dH * SH + od_dB * SB, od_K1 = SH - p.Wo * SW, od_K2 = SB - p.Ho * SH;
     const int a_step = BKP * (int)p.lddy * ESZ;
     const int b_const = ((b_kh - p.pad) * p.Wi + (b_kw - p.pad)) * ldxB + b_ci * ESZ;
+    // this lane's filter tap is fixed, so "source pixel inside the image" is a fixed range of output rows / columns:
+    // ho*stride - pad + kh in [0, Hi)  <=>  ho in [ho_lo, ho_lo + h_rng]  (one subtract + one unsigned compare)
+    const int ho_lo = max(0, (p.pad - b_kh + p.stride - 1) / p.stride), wo_lo = max(0, (p.pad - b_kw + p.stride - 1) / p.stride);
+    const int ho_hi = min(p.Ho - 1, (p.Hi - 1 + p.pad - b_kh) / p.stride), wo_hi = min(p.Wo - 1, (p.Wi - 1 + p.pad - b_kw) / p.stride);
+    const bool b_in = b_ok && ho_hi >= ho_lo && wo_hi >= wo_lo;
+    const unsigned h_rng = (unsigned)(ho_hi - ho_lo), w_rng = (unsigned)(wo_hi - wo_lo);
     int r_m[NPASS], r_ho[NPASS], r_wo[NPASS], r_pix[NPASS], r_a[NPASS];
 #pragma unroll
     for (int j = 0; j < NPASS; ++j) {
@@ -118,8 +124,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
         for (int j = 0; j < NPASS; ++j) {
             const bool m_ok = r_m[j] < p.M;
             const uint32_t aoff = (m_ok && a_ok) ? (uint32_t)r_a[j] : OOB;
-            const int sh = r_ho[j] * p.stride - p.pad + b_kh, sw = r_wo[j] * p.stride - p.pad + b_kw;
-            const bool ok = m_ok && b_ok && (unsigned)sh < (unsigned)p.Hi && (unsigned)sw < (unsigned)p.Wi;
+            const bool ok = m_ok && b_in && (unsigned)(r_ho[j] - ho_lo) <= h_rng && (unsigned)(r_wo[j] - wo_lo) <= w_rng;
             const uint32_t boff = ok ? (uint32_t)(r_pix[j] + b_const) : OOB;
             lds_dma16(yrs, adst + j * PASS_BYTES, aoff);
             lds_dma16(xrs, bdst + j * PASS_BYTES, boff);
