@@ -323,7 +323,7 @@ static int attn_check(const char* who, int B, int heads, int L, int S, int d, in
 struct AttnMP {
     const bf16_t *q, *k, *v, *o, *dout;
     bf16_t *out, *dq, *dk, *dv;
-    float* lse; const float* delta;
+    float* lse; float* delta;
     int64_t ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
     int B, H, L, S, d;
     float scale;
@@ -408,10 +408,8 @@ int psg_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const v
     dim3 gq((L + AT_Q - 1) / AT_Q, B * heads), gkv((S + AT_Q - 1) / AT_Q, B * heads);
     ProfScope prof(PROF_ATTN, 10.0 * (double)B * heads * L * S * d, s);
     if (attn_mfma_applicable(L, S, d, dtype, ldq, ldk, ldv, ldo) && ((lddo | lddq | lddk | lddv) & 7) == 0 && aligned16(q) && aligned16(k) &&
-        aligned16(v) && aligned16(dout) && aligned8(dq) && aligned8(dk) && aligned8(dv)) {
-        hipLaunchKernelGGL(attn_delta_kernel<bf16_t>, dim3(gdelta), dim3(256), 0, s, p);
-        PSG_LAUNCH_CHECK("attn_delta");
-        return attn_mfma_bwd(to_mfma(p), s);
+        aligned16(v) && aligned16(o) && aligned16(dout) && aligned8(dq) && aligned8(dk) && aligned8(dv)) {
+        return attn_mfma_bwd(to_mfma(p), s);       // (delta is produced inside the dQ kernel)
     }
     if (dtype == PSG_F32) {
         hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(gdelta), dim3(256), 0, s, p);

@@ -26,7 +26,7 @@ namespace psg {
 struct AttnMP {     // mirrored in attention.hip
     const bf16_t *q, *k, *v, *o, *dout;
     bf16_t *out, *dq, *dk, *dv;
-    float* lse; const float* delta;
+    float* lse; float* delta;                      // delta = rowsum(dO * O): written by the dQ kernel, read by dK/dV
     int64_t ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
     int B, H, L, S, d;
     float scale;
@@ -209,6 +209,7 @@ __global__ __launch_bounds__(256, (ND <= 5 ? 2 : 1)) void attn_dq_mfma(const Att
     const bf16_t* kg = p.k + (int64_t)b * p.S * p.ldk + hd * d;
     const bf16_t* vg = p.v + (int64_t)b * p.S * p.ldv + hd * d;
     const bf16_t* gg = p.dout + (int64_t)b * p.L * p.lddo + hd * d;
+    const bf16_t* og = p.o + (int64_t)b * p.L * p.ldo + hd * d;
     bf16_t* dqg = p.dq + (int64_t)b * p.L * p.lddq + hd * d;
     stage_tile(Ks, kg, p.ldk, 0, Sp, p.S, d, d, STR, tid, (int)blockDim.x);
     stage_tile(Vs, vg, p.ldv, 0, Sp, p.S, d, d, STR, tid, (int)blockDim.x);
@@ -230,7 +231,18 @@ __global__ __launch_bounds__(256, (ND <= 5 ? 2 : 1)) void attn_dq_mfma(const Att
             gf[ks] = *reinterpret_cast<bf16x8*>(&w);
         }
         const float lse = lok ? p.lse[(int64_t)bh * p.L + l] : 0.f;
-        const float del = lok ? p.delta[(int64_t)bh * p.L + l] : 0.f;
+        // delta_l = sum_d dO[l][d] * O[l][d]: this lane already holds its half of the dO row; O comes the same way
+        float del = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < ND; ++ks) {
+            const uint4 ov = *reinterpret_cast<const uint4*>(og + (int64_t)(lok ? l : 0) * p.ldo + 16 * ks + 8 * fh);
+            const bf16x8 of = *reinterpret_cast<const bf16x8*>(&ov);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) del += (float)gf[ks][j] * (float)of[j];
+        }
+        del += __shfl_xor(del, 32, 64);
+        if (!lok) del = 0.f;
+        if (lok && fh == 0) p.delta[(int64_t)bh * p.L + l] = del;
         f32x16 dacc[NDT];
 #pragma unroll
         for (int t = 0; t < NDT; ++t)
