@@ -186,8 +186,20 @@ def main():
                             "achieved": ach / (1e9 if is_bytes else 1e12), "unit": "GB/s" if is_bytes else "TFLOP/s",
                             "peak": 8000.0 if is_bytes else peak / 1e12, "frac": ach / (8e12 if is_bytes else peak)})
             dom = max(fam, key=lambda f: f["ms_per_step"])
+            # memory-side bytes per launch come from a SEPARATE rocprofv3 --pmc pass of this same command (PMC cannot
+            # be read from inside the process); the committed summary is attached when it covers the workload
+            traffic, traffic_src = None, None
+            tpath = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")
+            if B == 256 and args.dtype == "bf16" and os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))
+                    traffic = tj["families"][dom["kernel"]]["traffic_bytes_per_launch"]
+                    traffic_src = "profiles/r01_c_pmc_traffic.json: " + tj["correction"]
+                except Exception:                    # noqa: BLE001
+                    traffic = None
             res["roofline"] = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
-                               "frac": dom["frac"], "traffic": None, "kernel": dom["kernel"],
+                               "frac": dom["frac"], "traffic": traffic, "traffic_unit": "bytes/launch (memory-side requests incl. Infinity-Cache hits)",
+                               "traffic_source": traffic_src, "kernel": dom["kernel"],
                                "avg_launch_us": dom["avg_launch_us"], "launches_per_step": dom["launches_per_step"],
                                "ms_per_step": dom["ms_per_step"],
                                "how": "algorithmic 2*M*N*K FLOPs summed over the family's launches / HIP-event time on the launch stream"}
