@@ -66,6 +66,46 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {   // byte offset in
     return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4);
 }
 
+// Fused epilogue for 4 consecutive output channels n..n+3 of tile pixel mt (shared by both kernels):
+//   y = residual + alpha * drop(act(acc + bias + rowadd[b]))   or, with dact_u, the backward form * act'(u)
+template <typename T, int MODE>
+__device__ __forceinline__ void conv_emit(const ConvP& p, int mt, int n, f32x4 v) {
+    int b, m;
+    if (MODE == 3) {                                      // parity class: tile pixel -> row of y
+        const int hw = p.sub_nH * p.sub_nW;
+        b = mt / hw;
+        const int rm = mt - b * hw, i = rm / p.sub_nW, jj = rm - i * p.sub_nW;
+        m = (b * p.Ho + p.sub_h0 + 2 * i) * p.Wo + p.sub_w0 + 2 * jj;
+    } else {
+        b = mt / (p.Ho * p.Wo);
+        m = mt;
+    }
+    T* yg = reinterpret_cast<T*>(p.y);
+    const T* rag = reinterpret_cast<const T*>(p.rowadd);
+    const T* resg = reinterpret_cast<const T*>(p.residual);
+    T* preg = reinterpret_cast<T*>(p.preact);
+    const T* dug = reinterpret_cast<const T*>(p.dact_u);
+    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+    if (rag) v += load4<T>(rag + (int64_t)b * p.ldra + n);
+    if (preg) store4<T>(preg + (int64_t)m * p.ldpre + n, v);
+    if (dug) {          // backward form: multiply by act'(u) of the saved pre-activation
+        const f32x4 u = load4<T>(dug + (int64_t)m * p.lddact + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= act_grad(u[e], p.act);
+    } else if (p.act != PSG_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_f(v[e], p.act);
+    }
+    if (p.drop_thresh) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            v[e] = drop_keep(p.drop_seed, (uint64_t)m * p.N + n + e, p.drop_thresh) ? v[e] * p.drop_scale : 0.f;
+    }
+    v *= p.alpha;
+    if (resg) v += load4<T>(resg + (int64_t)m * p.ldres + n);
+    store4<T>(yg + (int64_t)m * p.ldy + n, v);
+}
+
 // MODE 0: forward gather, K step inside one tap (Cin % K-step == 0)   [every 3x3 / 1x1 layer of the U-Net body]
 // MODE 1: data-gradient gather of a stride-1 conv, same fast decode
 // MODE 2: generic (Cin = 8 first/last convs, odd channel counts): per-thread tap decode
@@ -327,56 +367,17 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(const ConvP p) {
     }
 
     // ---- fused epilogue ------------------------------------------------------
-    T* yg = reinterpret_cast<T*>(p.y);
-    const T* rag = reinterpret_cast<const T*>(p.rowadd);
-    const T* resg = reinterpret_cast<const T*>(p.residual);
-    T* preg = reinterpret_cast<T*>(p.preact);
-    const T* dug = reinterpret_cast<const T*>(p.dact_u);
-    const int HoWo = p.Ho * p.Wo;
-    auto out_row = [&](int m, int& b) {                   // tile pixel m -> row of y (and its sample index)
-        if (MODE == 3) {
-            const int hw = p.sub_nH * p.sub_nW;
-            b = m / hw;
-            const int rm = m - b * hw, i = rm / p.sub_nW, jj = rm - i * p.sub_nW;
-            return (b * p.Ho + p.sub_h0 + 2 * i) * p.Wo + p.sub_w0 + 2 * jj;
-        }
-        b = m / HoWo;
-        return m;
-    };
-    auto emit = [&](int m, int b, int n, f32x4 v) {       // 4 consecutive output channels n..n+3 of y row m
-        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
-        if (rag) v += load4<T>(rag + (int64_t)b * p.ldra + n);
-        if (preg) store4<T>(preg + (int64_t)m * p.ldpre + n, v);
-        if (dug) {          // backward form: multiply by act'(u) of the saved pre-activation
-            const f32x4 u = load4<T>(dug + (int64_t)m * p.lddact + n);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] *= act_grad(u[e], p.act);
-        } else if (p.act != PSG_ACT_NONE) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = act_f(v[e], p.act);
-        }
-        if (p.drop_thresh) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                v[e] = drop_keep(p.drop_seed, (uint64_t)m * p.N + n + e, p.drop_thresh) ? v[e] * p.drop_scale : 0.f;
-        }
-        v *= p.alpha;
-        if (resg) v += load4<T>(resg + (int64_t)m * p.ldres + n);
-        store4<T>(yg + (int64_t)m * p.ldy + n, v);
-    };
     if constexpr (FT16) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int mt_ = m0 + wm * WM + j * 16 + l16;
             if (mt_ >= p.M) continue;
-            int b;
-            const int m = out_row(mt_, b);
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const int n = n0 + wn * WN + i * 16 + 4 * kq;
                 if (n >= p.N) continue;
                 f32x4 v = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                emit(m, b, n, v);
+                conv_emit<T, MODE>(p, mt_, n, v);
             }
         }
     } else {
@@ -384,8 +385,6 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(const ConvP p) {
         for (int j = 0; j < NB; ++j) {
             const int mt_ = m0 + wm * WM + j * 32 + fr;
             if (mt_ >= p.M) continue;
-            int b;
-            const int m = out_row(mt_, b);
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
 #pragma unroll
@@ -393,13 +392,14 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(const ConvP p) {
                     const int n = n0 + wn * WN + i * 32 + 8 * g + 4 * fh;
                     if (n >= p.N) continue;
                     f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                    emit(m, b, n, v);
+                    conv_emit<T, MODE>(p, mt_, n, v);
                 }
             }
         }
     }
 #endif
 }
+
 
 template <typename T, int BM, int BN, int NT = 256, int NSTAGE = 2>
 static int launch_conv(const ConvP& p, hipStream_t stream) {
