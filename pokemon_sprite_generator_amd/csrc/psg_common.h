@@ -153,6 +153,11 @@ __device__ __forceinline__ u32x4 make_rsrc(const void* base, uint32_t bytes) {
 __device__ __forceinline__ void lds_dma16(const u32x4& rsrc, uint32_t lds_base, uint32_t voff) {
     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(lds_base), "v"(voff), "s"(rsrc) : "memory");
 }
+// same, with a wave-uniform byte offset in the instruction's scalar-offset operand (added to voff by the address
+// unit; the range check covers the sum), so lanes that step through memory by a uniform stride share ONE voff register
+__device__ __forceinline__ void lds_dma16s(const u32x4& rsrc, uint32_t lds_base, uint32_t voff, uint32_t soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_base), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // exact n / d for n < 2^24 using a float reciprocal and one correction step

@@ -32,7 +32,14 @@ template <typename T> struct WgCfg;
 template <> struct WgCfg<bf16_t> { static constexpr int BKP = 64; static constexpr int ROWB = 256; };  // bytes per LDS row
 template <> struct WgCfg<float> { static constexpr int BKP = 32; static constexpr int ROWB = 512; };
 
-template <typename T>
+// GEOM selects how the gathered-X row addresses are produced:
+//   0 general (stride 2, any padding): per-row (b, ho, wo) odometer
+//   1 "same" 3x3 (stride 1, Hi==Ho, Wi==Wo): the source pixel of tap (kh,kw) is m + const, so ONE address register
+//     steps linearly and the four staging passes differ only by a scalar offset; the image-border test needs just
+//     (m mod HoWo, m mod Wo) trackers per pass
+//   2 pointwise (1x1 conv / Linear): as 1 with no border at all
+// The per-lane address VALU work is what bounds this kernel (it competes with the MFMAs for issue slots).
+template <typename T, int GEOM>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // the LDS-DMA builtin exists only in the device pass
     constexpr int CH = Elem<T>::CH;
@@ -117,27 +124,63 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
     // (psg_common.h: lds_dma16) so hipcc does not drain it before the MFMA phase; waits are placed by hand.
     const uint32_t lds_wave = (uint32_t)(size_t)(lds_ptr_t)smem + (uint32_t)__builtin_amdgcn_readfirstlane(wave) * 1024u;
     constexpr int PASS_BYTES = RPP * ROWB;                                  // = 4096
+    // GEOM 1/2 state: pass 0's pixel and its two linear byte offsets; pass j adds the uniform j*RPP rows
+    int g_m = step0 * BKP + sr;
+    int g_a = (g_m * (int)p.lddy + a_co) * ESZ;
+    // hardware offsets are unsigned: the (possibly negative) tap shift is folded into a descriptor whose base sits
+    // pad rows + pad pixels BEFORE x, so the per-lane offset is >= 0; taps that would read below x are never valid
+    const int g_shift = (p.pad * p.Wi + p.pad) * ldxB;
+    const u32x4 xrs_g = make_rsrc(reinterpret_cast<const char*>(p.x) - g_shift, p.x_bytes + (uint32_t)g_shift);
+    int g_b = g_m * ldxB + (b_kh * p.Wi + b_kw) * ldxB + b_ci * ESZ;
+    const int a_pass = RPP * (int)p.lddy * ESZ, b_pass = RPP * ldxB;       // uniform
+    const int st_rm = BKP % HoWo, st_wo = BKP % p.Wo;
+    const int rm_lo = ho_lo * p.Wo;
+    const unsigned rm_rng = (unsigned)((ho_hi + 1) * p.Wo - 1 - rm_lo);
+    int g_rm[NPASS], g_wo[NPASS];
+#pragma unroll
+    for (int j = 0; j < NPASS; ++j) {
+        g_rm[j] = (g_m + RPP * j) % HoWo;
+        g_wo[j] = g_rm[j] % p.Wo;
+    }
     auto load_tiles = [&](int buf) {   // DMA the rows at the current odometer state into LDS buffer buf, then advance
         const uint32_t adst = lds_wave + (uint32_t)buf * 2 * TILE_BYTES;
         const uint32_t bdst = adst + TILE_BYTES;
+        if constexpr (GEOM == 0) {
 #pragma unroll
-        for (int j = 0; j < NPASS; ++j) {
-            const bool m_ok = r_m[j] < p.M;
-            const uint32_t aoff = (m_ok && a_ok) ? (uint32_t)r_a[j] : OOB;
-            const bool ok = m_ok && b_in && (unsigned)(r_ho[j] - ho_lo) <= h_rng && (unsigned)(r_wo[j] - wo_lo) <= w_rng;
-            const uint32_t boff = ok ? (uint32_t)(r_pix[j] + b_const) : OOB;
-            lds_dma16(yrs, adst + j * PASS_BYTES, aoff);
-            lds_dma16(xrs, bdst + j * PASS_BYTES, boff);
-            // advance by BKP pixels
-            r_m[j] += BKP; r_a[j] += a_step;
-            int wo = r_wo[j] + od_dW;
-            const bool c1 = wo >= p.Wo;
-            wo -= c1 ? p.Wo : 0;
-            int ho = r_ho[j] + od_dH + (c1 ? 1 : 0);
-            const bool c2 = ho >= p.Ho;
-            ho -= c2 ? p.Ho : 0;
-            r_wo[j] = wo; r_ho[j] = ho;
-            r_pix[j] += od_A0 + (c1 ? od_K1 : 0) + (c2 ? od_K2 : 0);
+            for (int j = 0; j < NPASS; ++j) {
+                const bool m_ok = r_m[j] < p.M;
+                const uint32_t aoff = (m_ok && a_ok) ? (uint32_t)r_a[j] : OOB;
+                const bool ok = m_ok && b_in && (unsigned)(r_ho[j] - ho_lo) <= h_rng && (unsigned)(r_wo[j] - wo_lo) <= w_rng;
+                const uint32_t boff = ok ? (uint32_t)(r_pix[j] + b_const) : OOB;
+                lds_dma16(yrs, adst + j * PASS_BYTES, aoff);
+                lds_dma16(xrs, bdst + j * PASS_BYTES, boff);
+                // advance by BKP pixels
+                r_m[j] += BKP; r_a[j] += a_step;
+                int wo = r_wo[j] + od_dW;
+                const bool c1 = wo >= p.Wo;
+                wo -= c1 ? p.Wo : 0;
+                int ho = r_ho[j] + od_dH + (c1 ? 1 : 0);
+                const bool c2 = ho >= p.Ho;
+                ho -= c2 ? p.Ho : 0;
+                r_wo[j] = wo; r_ho[j] = ho;
+                r_pix[j] += od_A0 + (c1 ? od_K1 : 0) + (c2 ? od_K2 : 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NPASS; ++j) {
+                const bool m_ok = g_m < p.M - RPP * j;
+                const uint32_t aoff = (m_ok && a_ok) ? (uint32_t)g_a : OOB;
+                bool ok = m_ok && b_in;
+                if constexpr (GEOM == 1) {
+                    ok = ok && (unsigned)(g_rm[j] - rm_lo) <= rm_rng && (unsigned)(g_wo[j] - wo_lo) <= w_rng;
+                    int rm = g_rm[j] + st_rm; rm -= rm >= HoWo ? HoWo : 0; g_rm[j] = rm;
+                    int wo = g_wo[j] + st_wo; wo -= wo >= p.Wo ? p.Wo : 0; g_wo[j] = wo;
+                }
+                const uint32_t boff = ok ? (uint32_t)g_b : OOB;
+                lds_dma16s(yrs, adst + j * PASS_BYTES, aoff, (uint32_t)(j * a_pass));
+                lds_dma16s(xrs_g, bdst + j * PASS_BYTES, boff, (uint32_t)(j * b_pass));
+            }
+            g_m += BKP; g_a += a_step; g_b += BKP * ldxB;
         }
     };
 
@@ -395,8 +438,11 @@ using namespace psg;
 extern "C" {
 
 int psg_wgrad_init_attrs(void) {
-    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<bf16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 256));
-    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32 * 512));
+#define PSG_WG_ATTR(G)                                                                                                                   \
+    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<bf16_t, G>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 64 * 256)); \
+    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<float, G>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32 * 512));
+    PSG_WG_ATTR(0) PSG_WG_ATTR(1) PSG_WG_ATTR(2)
+#undef PSG_WG_ATTR
     return PSG_OK;
 }
 
@@ -447,17 +493,22 @@ int psg_conv_wgrad(const psg_wgrad_desc* d, psg_stream_t stream) {
     p.inv_HoWo = 1.0f / (float)(d->Ho * d->Wo); p.inv_Wo = 1.0f / (float)d->Wo;
     {
         const int64_t esz = d->dtype == PSG_BF16 ? 2 : 4;
-        const int64_t xb = (((int64_t)d->B * d->Hi * d->Wi - 1) * d->ldx + d->Cin) * esz;
+        const int64_t xb = (((int64_t)d->B * d->Hi * d->Wi - 1) * d->ldx + d->Cin) * esz
+                           + (int64_t)(d->pad * d->Wi + d->pad) * d->ldx * esz;      // (+ the shifted-base slack of GEOM 1/2)
         const int64_t yb = (((int64_t)p.M - 1) * d->lddy + d->Cout) * esz;
         PSG_REQUIRE(xb < 0x7FFFFFF0ll && yb < 0x7FFFFFF0ll, PSG_ERR_SHAPE, "wgrad: operand extent >= 2 GiB");
-        p.x_bytes = (uint32_t)xb; p.dy_bytes = (uint32_t)yb;
+        p.x_bytes = (uint32_t)(xb - (int64_t)(d->pad * d->Wi + d->pad) * d->ldx * esz); p.dy_bytes = (uint32_t)yb;
     }
     const int grid = p.rtiles * p.qtiles * p.splits;
     hipStream_t s = (hipStream_t)stream;
     {
         ProfScope prof(PROF_WGRAD, 2.0 * (double)p.M * (double)p.Cout * (double)p.Q, s);
-        if (d->dtype == PSG_BF16) hipLaunchKernelGGL(wgrad_kernel<bf16_t>, dim3(grid), dim3(256), 4 * 64 * 256, s, p);
-        else hipLaunchKernelGGL(wgrad_kernel<float>, dim3(grid), dim3(256), 4 * 32 * 512, s, p);
+        const int geom = d->stride != 1 || d->Hi != d->Ho || d->Wi != d->Wo ? 0 : (d->ksize == 1 ? 2 : 1);
+#define PSG_WG_LAUNCH(G)                                                                                               \
+        if (d->dtype == PSG_BF16) hipLaunchKernelGGL((wgrad_kernel<bf16_t, G>), dim3(grid), dim3(256), 4 * 64 * 256, s, p); \
+        else hipLaunchKernelGGL((wgrad_kernel<float, G>), dim3(grid), dim3(256), 4 * 32 * 512, s, p);
+        if (geom == 0) { PSG_WG_LAUNCH(0) } else if (geom == 1) { PSG_WG_LAUNCH(1) } else { PSG_WG_LAUNCH(2) }
+#undef PSG_WG_LAUNCH
     }
     PSG_LAUNCH_CHECK("wgrad");
     const bool bias_pending = d->dbias && !bias_direct;
