@@ -193,10 +193,10 @@ typedef struct psg_wgrad_desc {
 int psg_conv_wgrad(const psg_wgrad_desc* d, psg_stream_t stream);
 int64_t psg_conv_wgrad_workspace_bytes(const psg_wgrad_desc* d);
 
-/* fp32 master weight (w_layout: PSG_W_OIHW or PSG_W_OHWI memory order) -> prepared forward weight wf [O][Kpad] with k=(kh,kw,ci) and prepared
- * data-gradient weight wd [I][Kpad'] with k=(kh,kw,co) (either may be NULL); zero K padding.
- * Returns Kpad for (ksize*ksize*C) via psg_kpad(). */
-int psg_prep_weight(const float* w, int w_layout, void* wf, void* wd, int O, int I, int ksize, int dtype,
+/* Master weight (w_dtype PSG_F32, or PSG_BF16 for the AdamW shadow copy; w_layout PSG_W_OIHW or PSG_W_OHWI memory
+ * order; a bf16 source must be OHWI or 1x1) -> prepared forward weight wf [O][Kpad] with k=(kh,kw,ci) and prepared
+ * data-gradient weight wd [I][Kpad'] with k=(kh,kw,co) (either may be NULL); zero K padding.  Kpad: psg_kpad(). */
+int psg_prep_weight(const void* w, int w_dtype, int w_layout, void* wf, void* wd, int O, int I, int ksize, int dtype,
                     psg_stream_t stream);
 int64_t psg_kpad(int64_t K, int dtype);
 
@@ -239,10 +239,12 @@ int psg_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const v
 int psg_sumsq_f32(const float* g, int64_t n, float* out, int accumulate, void* ws, psg_stream_t stream);
 /* clip_grad_norm_ (:410) fused with AdamW (:277-283,412): coef = min(1, max_norm/(sqrt(*normsq)+1e-6))
  * read on the device (normsq may be NULL = no clipping); decoupled weight decay; step is 1-based.
- * skip_flag (may be NULL): when *skip_flag != 0 the update is skipped (NaN batch, :383-393). */
+ * skip_flag (may be NULL): when *skip_flag != 0 the update is skipped (NaN batch, :383-393).
+ * shadow_bf16 (may be NULL): bf16 copy of the updated parameters written in the same pass, element i at
+ * shadow_bf16[i] — with OHWI master weights this IS the prepared forward weight of the next step. */
 int psg_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, const float* normsq,
-                  float max_norm, const int32_t* skip_flag, psg_stream_t stream);
+                  float max_norm, const int32_t* skip_flag, void* shadow_bf16, psg_stream_t stream);
 /* g *= min(1, max_norm/(sqrt(*normsq)+1e-6)) — plain clip for callers that keep torch.optim. */
 int psg_clip_scale_f32(float* g, int64_t n, const float* normsq, float max_norm, psg_stream_t stream);
 

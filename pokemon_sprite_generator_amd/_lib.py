@@ -69,7 +69,7 @@ SIGNATURES = {
     "psg_conv_fwd": (c_int, [C.POINTER(ConvDesc), c_void_p]),
     "psg_conv_wgrad": (c_int, [C.POINTER(WgradDesc), c_void_p]),
     "psg_conv_wgrad_workspace_bytes": (c_int64, [C.POINTER(WgradDesc)]),
-    "psg_prep_weight": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "psg_prep_weight": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "psg_kpad": (c_int64, [c_int64, c_int]),
     "psg_colsum": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "psg_colsum_workspace_bytes": (c_int64, [c_int64, c_int, c_int]),
@@ -81,7 +81,7 @@ SIGNATURES = {
     "psg_attn_bwd": (c_int, [c_void_p, c_int64] * 5 + [c_void_p, c_void_p] + [c_void_p, c_int64] * 3
                      + [c_int] * 5 + [c_float, c_float, c_uint64, c_int, c_void_p]),
     "psg_sumsq_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
-    "psg_adamw_f32": (c_int, [c_void_p] * 4 + [c_int64] + [c_float] * 5 + [c_int, c_void_p, c_float, c_void_p, c_void_p]),
+    "psg_adamw_f32": (c_int, [c_void_p] * 4 + [c_int64] + [c_float] * 5 + [c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "psg_clip_scale_f32": (c_int, [c_void_p, c_int64, c_void_p, c_float, c_void_p]),
     "psg_profile_begin": (c_int, []),
     "psg_profile_end": (c_int, [c_void_p, c_void_p, c_void_p, c_int]),

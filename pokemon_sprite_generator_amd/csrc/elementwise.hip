@@ -334,6 +334,32 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
     }
 }
 
+// float4 form for the flat arenas (n % 4 == 0, 16-byte aligned): same arithmetic per element, optional bf16 shadow
+__global__ void adamw_kernel4(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                              float* __restrict__ v, int64_t n4, float lr, float beta1, float beta2, float eps,
+                              float wd, float bc1, float bc2_sqrt, const float* normsq, float max_norm,
+                              const int32_t* skip_flag, bf16_t* __restrict__ shadow) {
+    if (skip_flag && *skip_flag) return;
+    const float coef = clip_coef_dev(normsq, max_norm);
+    const float step_size = lr / bc1;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 g4 = reinterpret_cast<const f32x4*>(g)[i];
+        f32x4 p4 = reinterpret_cast<f32x4*>(p)[i], m4 = reinterpret_cast<f32x4*>(m)[i], v4 = reinterpret_cast<f32x4*>(v)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gi = g4[e] * coef;
+            float pi = p4[e] * (1.0f - lr * wd);
+            const float mi = beta1 * m4[e] + (1.0f - beta1) * gi;
+            const float vi = beta2 * v4[e] + (1.0f - beta2) * gi * gi;
+            const float denom = sqrtf(vi) / bc2_sqrt + eps;
+            pi -= step_size * (mi / denom);
+            p4[e] = pi; m4[e] = mi; v4[e] = vi;
+        }
+        reinterpret_cast<f32x4*>(p)[i] = p4; reinterpret_cast<f32x4*>(m)[i] = m4; reinterpret_cast<f32x4*>(v)[i] = v4;
+        if (shadow) store4<bf16_t>(shadow + 4 * i, p4);
+    }
+}
+
 __global__ void clip_scale_kernel(float* __restrict__ g, int64_t n, const float* normsq, float max_norm) {
     const float coef = clip_coef_dev(normsq, max_norm);
     if (coef >= 1.0f) return;
@@ -394,8 +420,8 @@ __global__ void prep_weight_kernel(const float* __restrict__ w, int ohwi, T* __r
 // OHWI master (w[co][tap][ci], the training layout) or any 1x1/linear weight: one 64co x 64ci tile of one tap per
 // workgroup.  Shift-only index math, 256-byte coalesced reads, 8/16-byte stores of 4 elements along ci (wf) and
 // along co (wd, transposed through LDS).  Needs O % 4 == 0 and I % 4 == 0.
-template <typename T>
-__global__ __launch_bounds__(256) void prep_weight_ohwi_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd,
+template <typename S, typename T>
+__global__ __launch_bounds__(256) void prep_weight_ohwi_kernel(const S* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd,
                                                                int O, int I, int taps, int64_t kpf, int64_t kpd) {
     __shared__ float t[64][65];
     const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, tap = blockIdx.z;
@@ -406,7 +432,7 @@ __global__ __launch_bounds__(256) void prep_weight_ohwi_kernel(const float* __re
         for (int i = 0; i < 16; ++i) {
             const int co = i * 4 + rr;
             float v = 0.f;
-            if (co0 + co < O && ci0 + c < I) v = w[((int64_t)(co0 + co) * taps + tap) * I + ci0 + c];
+            if (co0 + co < O && ci0 + c < I) v = (float)w[((int64_t)(co0 + co) * taps + tap) * I + ci0 + c];
             t[co][c] = v;
         }
     }
@@ -579,11 +605,19 @@ int psg_sumsq_f32(const float* g, int64_t n, float* out, int accumulate, void* w
 
 int psg_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int step, const float* normsq, float max_norm,
-                  const int32_t* skip_flag, psg_stream_t stream) {
+                  const int32_t* skip_flag, void* shadow_bf16, psg_stream_t stream) {
     PSG_REQUIRE(p && g && m && v, PSG_ERR_ARG, "adamw: null pointer");
     PSG_REQUIRE(n > 0 && step >= 1, PSG_ERR_SHAPE, "adamw: n=%ld step=%d", (long)n, step);
     const float bc1 = 1.0f - powf(beta1, (float)step);
     const float bc2 = 1.0f - powf(beta2, (float)step);
+    const bool vec = n % 4 == 0 && aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v) && (!shadow_bf16 || aligned8(shadow_bf16));
+    PSG_REQUIRE(!shadow_bf16 || vec, PSG_ERR_ALIGN, "adamw: the bf16 shadow needs n %% 4 == 0 and 16-byte aligned buffers");
+    if (vec) {
+        hipLaunchKernelGGL(adamw_kernel4, dim3(grid_for(n / 4, 256, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n / 4, lr,
+                           beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), normsq, max_norm, skip_flag, (bf16_t*)shadow_bf16);
+        PSG_LAUNCH_CHECK("adamw");
+        return PSG_OK;
+    }
     hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr,
                        beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), normsq, max_norm, skip_flag);
     PSG_LAUNCH_CHECK("adamw");
@@ -720,10 +754,11 @@ int64_t psg_kpad(int64_t K, int dtype) {
     return (K + bk - 1) / bk * bk;
 }
 
-int psg_prep_weight(const float* w, int w_layout, void* wf, void* wd, int O, int I, int ksize, int dtype, psg_stream_t stream) {
+int psg_prep_weight(const void* w, int w_dtype, int w_layout, void* wf, void* wd, int O, int I, int ksize, int dtype, psg_stream_t stream) {
     PSG_REQUIRE(w && (wf || wd), PSG_ERR_ARG, "prep_weight: null pointer");
     PSG_REQUIRE(O > 0 && I > 0 && (ksize == 1 || ksize == 3), PSG_ERR_SHAPE, "prep_weight: O=%d I=%d k=%d", O, I, ksize);
     PSG_REQUIRE(w_layout == PSG_W_OIHW || w_layout == PSG_W_OHWI, PSG_ERR_ARG, "prep_weight: w_layout %d", w_layout);
+    PSG_REQUIRE(w_dtype == PSG_F32 || w_dtype == PSG_BF16, PSG_ERR_DTYPE, "prep_weight: w_dtype %d", w_dtype);
     const int ohwi = w_layout == PSG_W_OHWI;
     const int taps = ksize * ksize;
     const int64_t kpf = psg_kpad((int64_t)taps * I, dtype), kpd = psg_kpad((int64_t)taps * O, dtype);
@@ -731,16 +766,22 @@ int psg_prep_weight(const float* w, int w_layout, void* wf, void* wd, int O, int
     hipStream_t s = (hipStream_t)stream;
     if ((ohwi || taps == 1) && O % 4 == 0 && I % 4 == 0 && aligned16(w) && (!wf || aligned16(wf)) && (!wd || aligned16(wd))) {
         const dim3 g((I + 63) / 64, (O + 63) / 64, taps);
-        DISPATCH_DTYPE(dtype,
-            hipLaunchKernelGGL(prep_weight_ohwi_kernel<float>, g, dim3(256), 0, s, w, (float*)wf, (float*)wd, O, I, taps, kpf, kpd),
-            hipLaunchKernelGGL(prep_weight_ohwi_kernel<bf16_t>, g, dim3(256), 0, s, w, (bf16_t*)wf, (bf16_t*)wd, O, I, taps, kpf, kpd));
+        if (w_dtype == PSG_BF16) {
+            PSG_REQUIRE(dtype == PSG_BF16, PSG_ERR_DTYPE, "prep_weight: a bf16 source prepares bf16 weights only");
+            hipLaunchKernelGGL((prep_weight_ohwi_kernel<bf16_t, bf16_t>), g, dim3(256), 0, s, (const bf16_t*)w, (bf16_t*)wf, (bf16_t*)wd, O, I, taps, kpf, kpd);
+        } else {
+            DISPATCH_DTYPE(dtype,
+                hipLaunchKernelGGL((prep_weight_ohwi_kernel<float, float>), g, dim3(256), 0, s, (const float*)w, (float*)wf, (float*)wd, O, I, taps, kpf, kpd),
+                hipLaunchKernelGGL((prep_weight_ohwi_kernel<float, bf16_t>), g, dim3(256), 0, s, (const float*)w, (bf16_t*)wf, (bf16_t*)wd, O, I, taps, kpf, kpd));
+        }
         PSG_LAUNCH_CHECK("prep_weight");
         return PSG_OK;
     }
+    PSG_REQUIRE(w_dtype == PSG_F32, PSG_ERR_ARG, "prep_weight: a bf16 source must be OHWI (or 1x1), 16-byte aligned, O and I multiples of 4");
     const dim3 g((I + 31) / 32, (O + 31) / 32);
     DISPATCH_DTYPE(dtype,
-        hipLaunchKernelGGL(prep_weight_kernel<float>, dim3(g), dim3(256), 0, s, w, ohwi, (float*)wf, (float*)wd, O, I, taps, kpf, kpd),
-        hipLaunchKernelGGL(prep_weight_kernel<bf16_t>, dim3(g), dim3(256), 0, s, w, ohwi, (bf16_t*)wf, (bf16_t*)wd, O, I, taps, kpf, kpd));
+        hipLaunchKernelGGL(prep_weight_kernel<float>, dim3(g), dim3(256), 0, s, (const float*)w, ohwi, (float*)wf, (float*)wd, O, I, taps, kpf, kpd),
+        hipLaunchKernelGGL(prep_weight_kernel<bf16_t>, dim3(g), dim3(256), 0, s, (const float*)w, ohwi, (bf16_t*)wf, (bf16_t*)wd, O, I, taps, kpf, kpd));
     PSG_LAUNCH_CHECK("prep_weight");
     return PSG_OK;
 }

@@ -58,6 +58,30 @@ def weight_layout(t):
     return None
 
 
+class ParamShadow:
+    """Parameter -> (optim.ParamArena, index) for arenas that keep a bf16 shadow copy of the flat master buffer
+    (written by the AdamW kernel in its own pass).  For an OHWI / 2-D weight whose K needs no padding the shadow
+    slice IS the prepared forward weight, and the data-gradient operand is transposed from it (half the bytes)."""
+    _map = {}
+
+    @classmethod
+    def register(cls, param, arena, index):
+        cls._map[id(param)] = (arena, index, param)
+
+    @classmethod
+    def unregister_arena(cls, arena):
+        for k in [k for k, v in cls._map.items() if v[0] is arena]:
+            del cls._map[k]
+
+    @classmethod
+    def lookup(cls, param):
+        e = cls._map.get(id(param))
+        if e is None or e[2] is not param:
+            return None
+        arena, index, _ = e
+        return arena.shadow_slice(index)        # bf16 1-D tensor in sync with the parameter, or None
+
+
 class WeightCache:
     """fp32 master weight (OIHW or OHWI memory order) -> kernel-layout weights in the compute dtype.
 
@@ -91,13 +115,23 @@ class WeightCache:
         code = dtype_code(dtype)
         kpf = lib.psg_kpad(ks * ks * I, code)
         kpd = lib.psg_kpad(ks * ks * O, code)
-        wf = torch.empty((O, kpf), dtype=dtype, device=w.device)
-        wd = torch.empty((I, kpd), dtype=dtype, device=w.device) if need_wd else None
         src = w.detach()
         layout = weight_layout(src)
-        if layout is None:
-            src, layout = src.contiguous(), W_OIHW
-        check(lib.psg_prep_weight(ptr(src), layout, ptr(wf), ptr(wd), O, I, ks, code, stream_ptr()), "psg_prep_weight")
+        shadow = None
+        if dtype == torch.bfloat16 and kpf == ks * ks * I and O % 4 == 0 and I % 4 == 0 and (layout == W_OHWI or ks == 1):
+            shadow = ParamShadow.lookup(w)
+        wd = torch.empty((I, kpd), dtype=dtype, device=w.device) if need_wd else None
+        if shadow is not None:                     # the AdamW pass already wrote the forward operand
+            wf = shadow.view(O, kpf)
+            if need_wd:
+                check(lib.psg_prep_weight(ptr(shadow), dtype_code(torch.bfloat16), W_OHWI, None, ptr(wd), O, I, ks, code, stream_ptr()),
+                      "psg_prep_weight")
+        else:
+            wf = torch.empty((O, kpf), dtype=dtype, device=w.device)
+            if layout is None:
+                src, layout = src.contiguous(), W_OIHW
+            check(lib.psg_prep_weight(ptr(src), dtype_code(torch.float32), layout, ptr(wf), ptr(wd), O, I, ks, code, stream_ptr()),
+                  "psg_prep_weight")
         cls._entries[key] = (stamp, wf, wd, w)   # keep w alive so id() stays unique
         return wf, wd
 

@@ -16,14 +16,14 @@ import torch
 
 from . import _lib
 from ._lib import check, ptr, stream_ptr
-from .ops import GradSink, WeightCache
+from .ops import GradSink, ParamShadow, WeightCache
 
 
 def _arena_offsets(params):
     offsets, off = [], 0
     for p in params:
         offsets.append(off)
-        off += (p.numel() + 3) // 4 * 4              # keep every view 16-byte aligned
+        off += (p.numel() + 7) // 8 * 8              # 32-byte steps: fp32 views and their bf16 shadows stay 16-byte aligned
     return offsets, off
 
 
@@ -50,6 +50,34 @@ class ParamArena:
                 v.copy_(p.data)
                 p.data = v
         WeightCache.invalidate()
+        self.shadow = None               # bf16 copy of `flat`, kept current by FusedAdamW (enable_shadow)
+        self._shadow_epoch = -1
+        self._versions = None
+
+    def enable_shadow(self):
+        """Keep a bf16 shadow of the flat masters: FusedAdamW writes it in its update pass, ops.WeightCache uses
+        its slices as prepared forward weights.  A parameter changed by anything else (load_state_dict, manual
+        copy_) is detected through its torch version counter and prepared from the fp32 master until the next step."""
+        if self.shadow is None:
+            self.shadow = self.flat.to(torch.bfloat16)
+            for i, p in enumerate(self.params):
+                ParamShadow.register(p, self, i)
+        else:
+            self.shadow.copy_(self.flat)
+        self.mark_shadow_current()
+
+    def mark_shadow_current(self):
+        self._shadow_epoch = WeightCache.epoch
+        self._versions = [p._version for p in self.params]
+
+    def shadow_slice(self, index):
+        if self.shadow is None or self._shadow_epoch != WeightCache.epoch:
+            return None
+        p = self.params[index]
+        if p._version != self._versions[index]:
+            return None
+        o = self.offsets[index]
+        return self.shadow[o:o + p.numel()]
 
     def like(self, flat, index):
         """View of another flat buffer with parameter `index`'s offset, shape and strides."""
@@ -160,10 +188,13 @@ class FusedAdamW(torch.optim.Optimizer):
             b1, b2 = group["betas"]
             lib = _lib.init(self._pa.flat.device.index)
             self._step += 1
+            shadow = self._pa.shadow
             check(lib.psg_adamw_f32(ptr(self._pa.flat), ptr(self._ga.flat), ptr(self._m), ptr(self._v), self._pa.numel,
                                     float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
-                                    self._step, nptr, float(max_norm), fptr, stream_ptr()), "psg_adamw_f32")
+                                    self._step, nptr, float(max_norm), fptr, ptr(shadow), stream_ptr()), "psg_adamw_f32")
             WeightCache.invalidate()
+            if shadow is not None:
+                self._pa.mark_shadow_current()       # the kernel just rewrote it (a skipped NaN step leaves both untouched)
             return
         lib = None
         for group in self.param_groups:
@@ -184,5 +215,5 @@ class FusedAdamW(torch.optim.Optimizer):
                     g = torch.empty_like(p).copy_(g)
                 check(lib.psg_adamw_f32(ptr(p), ptr(g), ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]), p.numel(), float(group["lr"]),
                                         float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]), int(st["step"]),
-                                        nptr, float(max_norm), fptr, stream_ptr()), "psg_adamw_f32")
+                                        nptr, float(max_norm), fptr, None, stream_ptr()), "psg_adamw_f32")
         WeightCache.invalidate()     # parameters changed through raw pointers

@@ -14,6 +14,7 @@ TensorBoard) are NOT re-implemented: they are taken from the reference package
 `components=` (tests, benchmarks with synthetic latents).
 """
 import logging
+import os
 from pathlib import Path
 from typing import Any, Dict, Optional
 
@@ -57,6 +58,8 @@ class DiffusionStepper:
         self.lib = _lib.init(self.device.index if self.device.index is not None else torch.cuda.current_device())
         self.reducer = None
         self.params = ParamArena(unet.parameters())        # flat fp32 masters, conv weights OHWI
+        if getattr(unet, "compute_dtype", None) == torch.bfloat16 and optimizer_type == "adamw" and not os.environ.get("PSG_NO_SHADOW"):
+            self.params.enable_shadow()                     # AdamW also emits next step's bf16 forward weights
         self.arena = GradArena(unet.parameters(), on_ready=lambda i: self.reducer.on_ready(i) if self.reducer is not None else None)
         # Adam (non-decoupled decay) is torch's when asked for (:285-291); AdamW is the fused kernel (:277-283)
         if optimizer_type == "adamw":

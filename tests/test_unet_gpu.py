@@ -216,6 +216,32 @@ def test_train_step_updates_and_decreases_loss(psg):
         losses.append(float(r["loss"].item()))
         assert int(r["nan_flag"].item()) == 0
     assert losses[-1] < losses[0], losses
+    # the bf16 shadow written by the AdamW pass must equal a fresh preparation of the fp32 masters, bit for bit
+    from pokemon_sprite_generator_amd import ops, _lib
+    lib = _lib.init(0)
+    assert st.params.shadow is not None
+    checked = 0
+    for name, p in u.named_parameters():
+        if p.dim() not in (2, 4) or checked >= 12:
+            continue
+        ks = p.shape[2] if p.dim() == 4 else 1
+        O, I = p.shape[0], p.shape[1]
+        if (ks * ks * I) % 64 or O % 4 or I % 4:
+            continue
+        sh = ops.ParamShadow.lookup(p)
+        assert sh is not None, name
+        wf, wd = ops.WeightCache.get(p, torch.bfloat16, True)
+        assert wf.data_ptr() == sh.data_ptr(), "forward operand must be the shadow slice itself"
+        rf = torch.empty_like(wf); rd = torch.empty_like(wd)
+        lay = ops.weight_layout(p.detach())
+        _lib.check(lib.psg_prep_weight(_lib.ptr(p.detach()), 0, lay, _lib.ptr(rf), _lib.ptr(rd), O, I, ks, 1, _lib.stream_ptr()), "prep")
+        assert torch.equal(wf, rf) and torch.equal(wd, rd), name
+        checked += 1
+    assert checked >= 8
+    with torch.no_grad():                               # an out-of-band change must fall back to the fp32 master
+        w0 = dict(u.named_parameters())["down1.res1.conv1.weight"] if "down1.res1.conv1.weight" in dict(u.named_parameters()) else next(p for p in u.parameters() if p.dim() == 4 and p.shape[1] >= 64)
+        w0.mul_(1.0)
+    assert ops.ParamShadow.lookup(w0) is None
 
 
 def test_sampler_trace_golden(psg, golden, full_unets):
