@@ -18,11 +18,21 @@ class BucketedAllReduce:
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.overlap = overlap and self.flat.is_cuda
+        # RCCL averages inside the collective (ncclAvg): no extra pass over the 2.56 GB arena; gloo sums, then scales
+        self.avg_in_collective = False
+        if dist.is_initialized() and self.world > 1 and dist.get_backend(process_group) == "nccl":
+            try:                                   # every rank runs the same probe, so a refusal is collective too
+                probe = torch.ones(1, dtype=torch.float32, device=self.flat.device)
+                dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=process_group)
+                self.avg_in_collective = abs(float(probe.item()) - 1.0) < 1e-6
+            except Exception:                      # noqa: BLE001 - older RCCL without ncclAvg: sum, then scale
+                self.avg_in_collective = False
+        self.op = dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM
         self.buckets = []          # (start, end, [param indices])
         cap = max(1, bucket_bytes // 4)
         start, members = 0, []
         for i, (p, o) in enumerate(zip(params, offsets)):
-            end = o + (p.numel() + 3) // 4 * 4
+            end = offsets[i + 1] if i + 1 < len(offsets) else self.flat.numel()      # (includes the alignment gap)
             members.append(i)
             if end - start >= cap:
                 self.buckets.append((start, end, members))
@@ -58,9 +68,9 @@ class BucketedAllReduce:
         if self._stream is not None:
             self._stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self._stream):
-                w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                w = dist.all_reduce(view, op=self.op, group=self.group, async_op=True)
         else:
-            w = dist.all_reduce(view, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            w = dist.all_reduce(view, op=self.op, group=self.group, async_op=True)
         self._works.append(w)
 
     def finish(self):
@@ -76,5 +86,6 @@ class BucketedAllReduce:
             w.wait()
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
-        self.flat.mul_(1.0 / self.world)
+        if not self.avg_in_collective:
+            self.flat.mul_(1.0 / self.world)
         self.reset()
