@@ -342,21 +342,35 @@ __global__ void adamw_kernel4(float* __restrict__ p, const float* __restrict__ g
     if (skip_flag && *skip_flag) return;
     const float coef = clip_coef_dev(normsq, max_norm);
     const float step_size = lr / bc1;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        const f32x4 g4 = reinterpret_cast<const f32x4*>(g)[i];
-        f32x4 p4 = reinterpret_cast<f32x4*>(p)[i], m4 = reinterpret_cast<f32x4*>(m)[i], v4 = reinterpret_cast<f32x4*>(v)[i];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += 2 * stride) {
+        // two independent float4 groups per trip: 8 x 16-byte loads in flight per lane before the first use
+        const int64_t i1 = i0 + stride;
+        const bool two = i1 < n4;
+        const int64_t j1 = two ? i1 : i0;
+        f32x4 G[2] = {reinterpret_cast<const f32x4*>(g)[i0], reinterpret_cast<const f32x4*>(g)[j1]};
+        f32x4 P[2] = {reinterpret_cast<f32x4*>(p)[i0], reinterpret_cast<f32x4*>(p)[j1]};
+        f32x4 M[2] = {reinterpret_cast<f32x4*>(m)[i0], reinterpret_cast<f32x4*>(m)[j1]};
+        f32x4 V[2] = {reinterpret_cast<f32x4*>(v)[i0], reinterpret_cast<f32x4*>(v)[j1]};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float gi = g4[e] * coef;
-            float pi = p4[e] * (1.0f - lr * wd);
-            const float mi = beta1 * m4[e] + (1.0f - beta1) * gi;
-            const float vi = beta2 * v4[e] + (1.0f - beta2) * gi * gi;
-            const float denom = sqrtf(vi) / bc2_sqrt + eps;
-            pi -= step_size * (mi / denom);
-            p4[e] = pi; m4[e] = mi; v4[e] = vi;
+        for (int u = 0; u < 2; ++u) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float gi = G[u][e] * coef;
+                float pi = P[u][e] * (1.0f - lr * wd);
+                const float mi = beta1 * M[u][e] + (1.0f - beta1) * gi;
+                const float vi = beta2 * V[u][e] + (1.0f - beta2) * gi * gi;
+                const float denom = sqrtf(vi) / bc2_sqrt + eps;
+                pi -= step_size * (mi / denom);
+                P[u][e] = pi; M[u][e] = mi; V[u][e] = vi;
+            }
         }
-        reinterpret_cast<f32x4*>(p)[i] = p4; reinterpret_cast<f32x4*>(m)[i] = m4; reinterpret_cast<f32x4*>(v)[i] = v4;
-        if (shadow) store4<bf16_t>(shadow + 4 * i, p4);
+        reinterpret_cast<f32x4*>(p)[i0] = P[0]; reinterpret_cast<f32x4*>(m)[i0] = M[0]; reinterpret_cast<f32x4*>(v)[i0] = V[0];
+        if (shadow) store4<bf16_t>(shadow + 4 * i0, P[0]);
+        if (two) {
+            reinterpret_cast<f32x4*>(p)[i1] = P[1]; reinterpret_cast<f32x4*>(m)[i1] = M[1]; reinterpret_cast<f32x4*>(v)[i1] = V[1];
+            if (shadow) store4<bf16_t>(shadow + 4 * i1, P[1]);
+        }
     }
 }
 
