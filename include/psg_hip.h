@@ -181,6 +181,9 @@ typedef struct psg_wgrad_desc {
     int32_t accumulate;
     int32_t dw_layout;  /* psg_w_layout of dw */
     int32_t accumulate_bias;   /* like accumulate, for dbias */
+    float scale;               /* dw, dbias = scale * (...) — 0 is read as 1 (folds a constant output gate, e.g. the
+                                  0.7 / 0.8 attention gates of unet.py:220,238, into the gradient instead of a pass over dy) */
+    int32_t reserved1;
     int64_t ldx, lddy;
     const void* x;    /* forward input  [B,Hi,Wi,Cin] */
     const void* dy;   /* output grad    [B,Ho,Wo,Cout] */

@@ -38,7 +38,7 @@ class WgradDesc(C.Structure):
         ("dtype", C.c_int32), ("B", C.c_int32), ("Hi", C.c_int32), ("Wi", C.c_int32), ("Cin", C.c_int32),
         ("Ho", C.c_int32), ("Wo", C.c_int32), ("Cout", C.c_int32),
         ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32), ("accumulate", C.c_int32),
-        ("dw_layout", C.c_int32), ("accumulate_bias", C.c_int32),
+        ("dw_layout", C.c_int32), ("accumulate_bias", C.c_int32), ("scale", C.c_float), ("reserved1", C.c_int32),
         ("ldx", C.c_int64), ("lddy", C.c_int64),
         ("x", c_void_p), ("dy", c_void_p), ("dw", c_void_p), ("dbias", c_void_p), ("ws", c_void_p), ("ws_bytes", C.c_int64),
     ]

@@ -20,6 +20,7 @@ namespace psg {
 struct WgP {
     const void* x; const void* dy; float* ws;
     float* bws;                                    // bias-gradient partials [splits][Cout] (or dbias itself), NULL = none
+    float scale;                                   // constant factor folded into every partial
     int64_t ldx, lddy;
     int B, Hi, Wi, Cin, Ho, Wo, Cout, ks, stride, pad;
     int M, Q, taps;
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const int co = co0 + wr * 64 + i * 16 + 4 * (lane >> 4) + r;
-                        if (co < p.Cout) bw[co] = accb[i][r];
+                        if (co < p.Cout) bw[co] = accb[i][r] * p.scale;
                     }
             }
         } else {
@@ -302,7 +303,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int co = co0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                        if (co < p.Cout) bw[co] = accb[i][r];
+                        if (co < p.Cout) bw[co] = accb[i][r] * p.scale;
                     }
             }
         }
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int co = co0 + wr * 64 + i * 16 + 4 * kq + r;
-                    if (co < p.Cout) wsb[(int64_t)co * p.Q + q] = acc[i][j][r];
+                    if (co < p.Cout) wsb[(int64_t)co * p.Q + q] = acc[i][j][r] * p.scale;
                 }
             }
         }
@@ -333,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int co = co0 + wr * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * fh;
-                    if (co < p.Cout) wsb[(int64_t)co * p.Q + q] = acc[i][j][r];
+                    if (co < p.Cout) wsb[(int64_t)co * p.Q + q] = acc[i][j][r] * p.scale;
                 }
             }
         }
@@ -487,6 +488,7 @@ int psg_conv_wgrad(const psg_wgrad_desc* d, psg_stream_t stream) {
         PSG_REQUIRE(d->ws_bytes >= (slab_floats + bias_floats) * (int64_t)sizeof(float), PSG_ERR_WORKSPACE, "wgrad: workspace too small");
     }
     p.x = d->x; p.dy = d->dy; p.ws = direct ? d->dw : (float*)d->ws; p.ldx = d->ldx; p.lddy = d->lddy;
+    p.scale = d->scale == 0.f ? 1.0f : d->scale;
     p.bws = !d->dbias ? nullptr : (bias_direct ? d->dbias : (float*)d->ws + slab_floats);
     p.B = d->B; p.Hi = d->Hi; p.Wi = d->Wi; p.Cin = d->Cin; p.Ho = d->Ho; p.Wo = d->Wo; p.Cout = d->Cout;
     p.ks = d->ksize; p.stride = d->stride; p.pad = d->pad;

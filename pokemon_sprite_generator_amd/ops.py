@@ -199,13 +199,14 @@ def _conv_launch(lib, dtype, x, ldx, w, ldw, y, ldy, geom, Cin, Cout, transposed
     check(lib.psg_conv_fwd(C.byref(d), stream_ptr()), "psg_conv_fwd")
 
 
-def _wgrad_launch(lib, dtype, x, ldx, dy, lddy, dw, geom, Cin, Cout, accumulate=False, dbias=None, accumulate_bias=False):
+def _wgrad_launch(lib, dtype, x, ldx, dy, lddy, dw, geom, Cin, Cout, accumulate=False, dbias=None, accumulate_bias=False, scale=1.0):
     """dw (+)= dy^T . gather(x); with `dbias` the same launch also produces the bias gradient (column sums of dy)."""
     B, Hi, Wi, Ho, Wo, ks, stride, pad = geom
     d = WgradDesc()
     d.dtype = dtype_code(dtype)
     d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout = B, Hi, Wi, Cin, Ho, Wo, Cout
     d.ksize, d.stride, d.pad, d.accumulate = ks, stride, pad, int(accumulate)
+    d.scale = float(scale)
     d.ldx, d.lddy = ldx, lddy
     layout = weight_layout(dw)
     out = dw
@@ -321,8 +322,13 @@ class _ConvFn(torch.autograd.Function):
         dyr, lddy = _rows(dy)
         M = B * Ho * Wo
         d_res = dy if has_res else None
-        # gradient w.r.t. the pre-epilogue accumulator
-        if act != ACT_NONE or drop_p > 0.0 or alpha != 1.0:
+        # gradient w.r.t. the pre-epilogue accumulator; a pure output gate (alpha only) is folded into the dgrad
+        # epilogue and the wgrad scale instead of a pass over dy
+        gate = 1.0
+        if act == ACT_NONE and drop_p == 0.0 and alpha != 1.0 and not has_ra:
+            gate = float(alpha)
+            g, ldg = dyr, lddy
+        elif act != ACT_NONE or drop_p > 0.0 or alpha != 1.0:
             g = torch.empty((M, Cout), dtype=dtype, device=dy.device)
             check(lib.psg_epilogue_bwd(ptr(dyr), lddy, ptr(preact), Cout, ptr(g), Cout, M, Cout, act, float(alpha), float(drop_p),
                                        int(seed), dtype_code(dtype), stream_ptr()), "psg_epilogue_bwd")
@@ -335,18 +341,24 @@ class _ConvFn(torch.autograd.Function):
                 _, wd = WeightCache.get(weight, dtype, True)
             dx = torch.empty(x_shape, dtype=dtype, device=dy.device)
             tgeom = (B, Ho, Wo, Hi, Wi, ks, stride, pad)     # gather source = dY grid, result = input grid
-            _conv_launch(lib, dtype, g, ldg, wd, 0, dx, Cin, tgeom, Cout, Cin, transposed=True)
+            _conv_launch(lib, dtype, g, ldg, wd, 0, dx, Cin, tgeom, Cout, Cin, transposed=True, alpha=gate)
         want_b = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             # one launch: weight gradient + (fused) bias gradient, straight into the gradient arena when registered
             wo, wacc, we = _param_out(ctx.weight_param)
             bo, bacc, be = _param_out(ctx.bias_param) if want_b else (None, False, None)
-            _wgrad_launch(lib, dtype, xr, ldx, g, ldg, wo, geom, Cin, Cout, accumulate=wacc, dbias=bo, accumulate_bias=bacc)
+            _wgrad_launch(lib, dtype, xr, ldx, g, ldg, wo, geom, Cin, Cout, accumulate=wacc, dbias=bo, accumulate_bias=bacc, scale=gate)
             dw = _param_ret(wo, we)
             if want_b:
                 db = _param_ret(bo, be)
         elif want_b:
-            db = _param_grad(ctx.bias_param, lambda out, acc: _colsum(lib, g, ldg, M, 1, Cout, dtype, torch.float32, out=out, accumulate=acc))
+            def bias_only(out, acc):
+                if gate == 1.0:
+                    _colsum(lib, g, ldg, M, 1, Cout, dtype, torch.float32, out=out, accumulate=acc)
+                else:                      # (rare: frozen weight, trainable bias, gated output)
+                    t = _colsum(lib, g, ldg, M, 1, Cout, dtype, torch.float32).mul_(gate)
+                    out.add_(t) if acc else out.copy_(t)
+            db = _param_grad(ctx.bias_param, bias_only)
         if has_ra and ctx.needs_input_grad[3]:
             dra = _colsum(lib, g, ldg, Ho * Wo, B, Cout, dtype, dtype, keep2d=True)
         return dx, dw, db, dra, d_res, None, None, None, None, None
