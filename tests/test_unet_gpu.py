@@ -258,9 +258,15 @@ def test_sampler_trace_golden(psg, golden, full_unets):
         return hashgen.uniform(tuple(shape), cases.INPUT_SEED, hashgen.name_id(nm)) * math.sqrt(3.0)
 
     trace = []
-    x = st.sample(text.to(DEV), n, True, noise_fn, trace=trace)
+    x = st.sample(text.to(DEV), n, True, noise_fn, trace=trace, use_graph=True)
     assert len(trace) == 20
     for i in (0, 4, 9, 14, 19):
         e = maxrel(trace[i], torch.from_numpy(g[f"x_step{i}"]))
         assert e < 5e-3, f"sampler step {i}: {e}"          # 20 chained U-Net calls; per-call bar is 1e-3
     assert maxrel(x, torch.from_numpy(g["x_final"])) < 5e-3
+    # that ran as a captured hipGraph of the step replayed 19 times; the eager path must give the same bits
+    trace_e = []
+    xe = st.sample(text.to(DEV), n, True, noise_fn, trace=trace_e, use_graph=False)
+    assert len(trace_e) == 20 and torch.equal(xe, x)
+    for a, b in zip(trace, trace_e):
+        assert torch.equal(a, b)
