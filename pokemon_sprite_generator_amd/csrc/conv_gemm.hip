@@ -111,16 +111,14 @@ __device__ __forceinline__ void conv_emit(const ConvP& p, int mt, int n, f32x4 v
 // MODE 2: generic (Cin = 8 first/last convs, odd channel counts): per-thread tap decode
 // MODE 3: stride-2 data gradient, one launch per output-pixel parity class: on the class's own (i, j) grid the
 //         gather is a stride-1 gather with 1, 2 or 4 taps (table in ConvP) instead of 9 taps of which 3/4 miss
-// NT threads (256: 4 waves as 2m x 2n; 512: 8 waves as 4m x 2n), NSTAGE LDS tile buffers:
-//   NSTAGE 2: the tile of step kt+1 is requested at the top of step kt (plain __syncthreads, drains vmcnt)
-//   NSTAGE 3: the tile of step kt+2 is requested at the top of step kt and stays in flight ACROSS the barrier
-//             (counted s_waitcnt vmcnt + raw s_barrier): two MFMA phases to hide the L2/HBM round trip
-template <typename T, int BM, int BN, int MODE, int NT, int NSTAGE>
-__global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(const ConvP p) {
+// 256 threads = 4 waves (2 along m x 2 along n), two LDS tile buffers: the tile of step kt+1 is requested at the top
+// of step kt (plain __syncthreads at the end of the step).
+template <typename T, int BM, int BN, int MODE>
+__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // the LDS-DMA builtin exists only in the device pass
+    constexpr int NT = 256;
     constexpr int CH = Elem<T>::CH;
-    constexpr int WAVES_M = NT / 128;           // waves along m (2 along n)
-    constexpr int WM = BM / WAVES_M, WN = BN / 2;           // pixels / channels per wave (BN = 160 -> 80 = 5 x 16: bf16 only)
+    constexpr int WM = BM / 2, WN = BN / 2;           // pixels / channels per wave (BN = 160 -> 80 = 5 x 16: bf16 only)
     constexpr int RPP = NT / 8;                 // rows per staging pass (8 lanes x 16 B per 128-byte row)
     constexpr int JX = BM / RPP, JW = BN / RPP; // staging passes
     constexpr int PASS_BYTES = RPP * 128;
@@ -327,43 +325,16 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(const ConvP p) {
     };
 
     const int KT = p.KT;
-    if constexpr (NSTAGE == 2) {
-        load_tiles(0, 0);
-        wait_vmcnt<0>();
-        __syncthreads();                       // the DMA of tile 0 has landed for every wave
-        for (int kt = 0; kt < KT; ++kt) {
-            const int buf = kt & 1;
-            // buffer buf^1 was last read in step kt-1, which every wave finished before the barrier below
-            if (kt + 1 < KT) load_tiles(kt + 1, buf ^ 1);
-            compute(buf);
-            wait_vmcnt<0>();                   // (asm LDS-DMA is invisible to hipcc: the wait is ours)
-            __syncthreads();                   // tile kt+1 is in LDS, tile kt no longer needed
-        }
-    } else {
-        // 3-stage ring.  Each wave issues JW+JX LDS-DMA instructions per tile, in order; "vmcnt(JW+JX)" therefore
-        // means "everything except the youngest tile has landed".  The barrier is the raw s_barrier: __syncthreads()
-        // would add vmcnt(0) and drain the tile that is meant to stay in flight.
-        constexpr int PER_TILE = JW + JX;
-        load_tiles(0, 0);
-        if (KT > 1) {
-            load_tiles(1, 1);
-            wait_vmcnt<PER_TILE>();
-        } else {
-            wait_vmcnt<0>();
-        }
-        __builtin_amdgcn_s_barrier();
-        int cur = 0, nxt2 = 2;                 // stage holding tile kt, stage that will receive tile kt+2
-        for (int kt = 0; kt < KT; ++kt) {
-            // stage nxt2 held tile kt-1: every wave finished reading it before the barrier that ended step kt-1
-            if (kt + 2 < KT) load_tiles(kt + 2, nxt2);
-            compute(cur);
-            // tile kt+1 must have landed (for every wave) before step kt+1; tile kt+2 may stay in flight
-            if (kt + 2 < KT) wait_vmcnt<PER_TILE>();
-            else wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            cur = cur == 2 ? 0 : cur + 1;
-            nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
-        }
+    load_tiles(0, 0);
+    wait_vmcnt<0>();
+    __syncthreads();                       // the DMA of tile 0 has landed for every wave
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        // buffer buf^1 was last read in step kt-1, which every wave finished before the barrier below
+        if (kt + 1 < KT) load_tiles(kt + 1, buf ^ 1);
+        compute(buf);
+        wait_vmcnt<0>();                   // (asm LDS-DMA is invisible to hipcc: the wait is ours)
+        __syncthreads();                   // tile kt+1 is in LDS, tile kt no longer needed
     }
 
     // ---- fused epilogue ------------------------------------------------------
@@ -401,31 +372,31 @@ __global__ __launch_bounds__(NT, 2) void conv_gemm_kernel(const ConvP p) {
 }
 
 
-template <typename T, int BM, int BN, int NT = 256, int NSTAGE = 2>
+template <typename T, int BM, int BN>
 static int launch_conv(const ConvP& p, hipStream_t stream) {
-    const size_t lds = (size_t)NSTAGE * (BM + BN) * 128;
+    const size_t lds = (size_t)2 * (BM + BN) * 128;
     ConvP q = p;
     q.mtiles = (p.M + BM - 1) / BM;
     q.ntiles = (p.N + BN - 1) / BN;
     const int grid = q.mtiles * q.ntiles;
     ProfScope prof(p.transposed ? PROF_CONV_DGRAD : PROF_CONV_FWD, 2.0 * (double)p.M * (double)p.N * (double)p.taps * (double)p.Cin, stream);
     const int mode = p.ntap > 0 ? 3 : (!p.fast ? 2 : (!p.transposed ? 0 : (p.stride == 1 ? 1 : 2)));
-    if (mode == 3) hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 3, NT, NSTAGE>), dim3(grid), dim3(NT), lds, stream, q);
-    else if (mode == 0) hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 0, NT, NSTAGE>), dim3(grid), dim3(NT), lds, stream, q);
-    else if (mode == 1) hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 1, NT, NSTAGE>), dim3(grid), dim3(NT), lds, stream, q);
-    else hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 2, NT, NSTAGE>), dim3(grid), dim3(NT), lds, stream, q);
+    if (mode == 3) hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 3>), dim3(grid), dim3(256), lds, stream, q);
+    else if (mode == 0) hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 0>), dim3(grid), dim3(256), lds, stream, q);
+    else if (mode == 1) hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 1>), dim3(grid), dim3(256), lds, stream, q);
+    else hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 2>), dim3(grid), dim3(256), lds, stream, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "conv_gemm launch");
     return PSG_OK;
 }
 
-template <typename T, int BM, int BN, int NT = 256, int NSTAGE = 2>
+template <typename T, int BM, int BN>
 static int set_conv_attrs() {
-    const int lds = NSTAGE * (BM + BN) * 128;
-    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 0, NT, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 1, NT, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 2, NT, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 3, NT, NSTAGE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    const int lds = 2 * (BM + BN) * 128;
+    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     return PSG_OK;
 }
 
@@ -436,25 +407,20 @@ static int choose_and_launch(const ConvP& p, int dtype, hipStream_t s) {
     {
         static int force = -2;                             // PSG_CONV_TILE=0..3 pins a candidate (kernel A/B runs)
         if (force == -2) { const char* e = getenv("PSG_CONV_TILE"); force = e ? atoi(e) : -1; }
-        const int cand[5][2] = {{256, 128}, {128, 128}, {128, 64}, {64, 64}, {128, 160}};
-        double eff[5] = {0.90, 1.0, 0.78, 0.55, 1.0};      // measured relative MFMA efficiency of the tile shapes
-        if (p.KT <= 10) eff[2] = 1.1;                      // K <= 640: 3 resident 128x64 workgroups hide the short K loop's ends
-        if (dtype != PSG_BF16) eff[4] = 0.0;               // 160 = 2 x 5 x 16: only the 16x16x32 bf16 tiles divide it
-        const double slots_of[5] = {256.0, 512.0, 512.0, 512.0, 512.0};   // resident workgroups on the chip
+        const int cand[4][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 160}};
+        double eff[4] = {1.0, 0.78, 0.55, 1.0};            // measured relative MFMA efficiency of the tile shapes
+        if (p.KT <= 10) eff[1] = 1.1;                      // K <= 640: 3 resident 128x64 workgroups hide the short K loop's ends
+        if (dtype != PSG_BF16) eff[3] = 0.0;               // 160 = 2 x 5 x 16: only the 16x16x32 bf16 tiles divide it
+        const double slots = 512.0;                        // resident workgroups on the chip (2 per CU)
         double best = -1.0;
-        for (int c = 0; c < 5; ++c) {
+        for (int c = 0; c < 4; ++c) {
             const double tiles = (double)((M + cand[c][0] - 1) / cand[c][0]) * (double)((p.N + cand[c][1] - 1) / cand[c][1]);
             const double useful = (double)M * p.N / (tiles * cand[c][0] * cand[c][1]);
-            const double waves = ceil(tiles / slots_of[c]);
-            double score = useful * (tiles / (waves * slots_of[c])) * eff[c];
-            if (c == 0 && p.KT < 4) score = 0.0;           // the 3-stage ring needs a few K steps to pay off
+            const double waves = ceil(tiles / slots);
+            double score = useful * (tiles / (waves * slots)) * eff[c];
             if (force >= 0) score = (c == force) ? 1.0 : 0.0;
             if (score > best) { best = score; BM = cand[c][0]; BN = cand[c][1]; }
         }
-    }
-    if (BM == 256) {
-        if (dtype == PSG_F32) return launch_conv<float, 256, 128, 512, 3>(p, s);
-        return launch_conv<bf16_t, 256, 128, 512, 3>(p, s);
     }
     if (BN == 160) return launch_conv<bf16_t, 128, 160>(p, s);
     if (dtype == PSG_F32) {
@@ -482,8 +448,6 @@ int psg_conv_init_attrs(void) {
     if ((rc = set_conv_attrs<float, 64, 64>())) return rc;
     if ((rc = set_conv_attrs<bf16_t, 64, 64>())) return rc;
     if ((rc = set_conv_attrs<bf16_t, 128, 160>())) return rc;
-    if ((rc = set_conv_attrs<float, 256, 128, 512, 3>())) return rc;
-    if ((rc = set_conv_attrs<bf16_t, 256, 128, 512, 3>())) return rc;
     return PSG_OK;
 }
 

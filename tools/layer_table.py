@@ -44,11 +44,11 @@ def conv_hook(lib_, dtype, x, ldx, w, ldw, y, ldy, geom, Cin, Cout, transposed=F
     timed(key, flops, lambda: orig_conv(lib_, dtype, x, ldx, w, ldw, y, ldy, geom, Cin, Cout, transposed=transposed, **kw))
 
 
-def wgrad_hook(lib_, dtype, x, ldx, dy, lddy, dw, geom, Cin, Cout, accumulate=False):
+def wgrad_hook(lib_, dtype, x, ldx, dy, lddy, dw, geom, Cin, Cout, accumulate=False, **kw):
     Bq, Hi, Wi, Ho, Wo, ks, stride, pad = geom
     flops = 2.0 * Bq * Ho * Wo * Cout * Cin * ks * ks
     key = ("wgrad", geom, Cin, Cout, ldx, lddy)
-    timed(key, flops, lambda: orig_wgrad(lib_, dtype, x, ldx, dy, lddy, dw, geom, Cin, Cout, accumulate=accumulate))
+    timed(key, flops, lambda: orig_wgrad(lib_, dtype, x, ldx, dy, lddy, dw, geom, Cin, Cout, accumulate=accumulate, **kw))
 
 
 ops._conv_launch, ops._wgrad_launch = conv_hook, wgrad_hook
@@ -60,5 +60,5 @@ print("%-6s %-34s %5s %9s %9s %8s" % ("kind", "B,Hi,Wi,Ho,Wo,k,s,p Cin->Cout", "
 for (kind, geom, Cin, Cout, ldx, ldy), (ms, n, fl) in rows:
     tot[kind] += ms * n
     if ms * n > 0.25:
-        print("%-6s %-34s %5d %9.1f %9.3f %8.1f" % (kind, ",".join(map(str, geom[1:])) + f" {Cin}->{Cout}" + (f" ldx{ldx}" if ldx != Cin else ""), n, ms * 1e3, ms * n, fl / ms / 1e9))
+        print("%-6s %-40s %5d %9.1f %9.3f %8.1f" % (kind, f"M{geom[0]*geom[3]*geom[4]} " + ",".join(map(str, geom[1:])) + f" {Cin}->{Cout}" + (f" ldx{ldx}" if ldx != Cin else ""), n, ms * 1e3, ms * n, fl / ms / 1e9))
 print({k: round(v, 2) for k, v in tot.items()})
