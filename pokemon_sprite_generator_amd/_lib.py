@@ -150,7 +150,9 @@ _ws = {}
 
 
 def workspace(nbytes: int, device):
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    # one buffer per (device, stream): kernels on one stream run in order, so they can share scratch; a second
+    # stream (ops: weight gradients overlapped with data gradients) gets its own
+    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)

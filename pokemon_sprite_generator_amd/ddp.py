@@ -67,6 +67,9 @@ class BucketedAllReduce:
         view = self.flat[s:e]
         if self._stream is not None:
             self._stream.wait_stream(torch.cuda.current_stream())
+            from .ops import SideStream            # weight gradients are produced on the side stream
+            if SideStream.enabled and self.flat.is_cuda:
+                self._stream.wait_stream(SideStream.get(self.flat.device))
             with torch.cuda.stream(self._stream):
                 w = dist.all_reduce(view, op=self.op, group=self.group, async_op=True)
         else:

@@ -6,6 +6,7 @@ here launches hand-written HIP kernels on torch's current stream; PyTorch only
 owns the memory.  There is no eager fallback: tensors must be on a GPU.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -241,6 +242,30 @@ def _colsum(lib, a, lda, R, groups, cols, dtype, out_dtype, keep2d=False, out=No
     return out
 
 
+class SideStream:
+    """Second HIP stream for the weight-gradient GEMMs of backward: wgrad depends only on the saved input and dY and
+    nothing else in backward depends on it, so it fills the tail waves of the data-gradient GEMM that runs next on
+    the main stream (-1.5 % step time).  Used only for gradients that go to a GradSink (optim.GradArena): the arena's
+    finalize() joins the stream before anything reads the gradients.  PSG_WGRAD_STREAM=0 disables it."""
+    enabled = os.environ.get("PSG_WGRAD_STREAM", "1") != "0"
+    _streams = {}
+    used = False
+
+    @classmethod
+    def get(cls, device):
+        k = device.index if device.index is not None else torch.cuda.current_device()
+        s = cls._streams.get(k)
+        if s is None:
+            s = cls._streams[k] = torch.cuda.Stream(device=device)
+        return s
+
+    @classmethod
+    def join(cls, device):
+        if cls.used:
+            torch.cuda.current_stream(device).wait_stream(cls.get(device))
+            cls.used = False
+
+
 def _param_out(param):
     """(out, accumulate, sink entry or None) for a parameter gradient: the registered sink view or a fresh tensor."""
     e = GradSink.get(param)
@@ -347,7 +372,15 @@ class _ConvFn(torch.autograd.Function):
             # one launch: weight gradient + (fused) bias gradient, straight into the gradient arena when registered
             wo, wacc, we = _param_out(ctx.weight_param)
             bo, bacc, be = _param_out(ctx.bias_param) if want_b else (None, False, None)
-            _wgrad_launch(lib, dtype, xr, ldx, g, ldg, wo, geom, Cin, Cout, accumulate=wacc, dbias=bo, accumulate_bias=bacc, scale=gate)
+            if SideStream.enabled and we is not None:
+                side, cur = SideStream.get(dy.device), torch.cuda.current_stream(dy.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    _wgrad_launch(lib, dtype, xr, ldx, g, ldg, wo, geom, Cin, Cout, accumulate=wacc, dbias=bo, accumulate_bias=bacc, scale=gate)
+                g.record_stream(side); xr.record_stream(side)
+                SideStream.used = True
+            else:
+                _wgrad_launch(lib, dtype, xr, ldx, g, ldg, wo, geom, Cin, Cout, accumulate=wacc, dbias=bo, accumulate_bias=bacc, scale=gate)
             dw = _param_ret(wo, we)
             if want_b:
                 db = _param_ret(bo, be)

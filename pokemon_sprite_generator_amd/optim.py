@@ -16,7 +16,7 @@ import torch
 
 from . import _lib
 from ._lib import check, ptr, stream_ptr
-from .ops import GradSink, ParamShadow, WeightCache
+from .ops import GradSink, ParamShadow, SideStream, WeightCache
 
 
 def _arena_offsets(params):
@@ -115,13 +115,16 @@ class GradArena:
                 p.grad = v
 
     def finalize(self):
-        """After backward: parameters that received no gradient this step get an explicit zero."""
+        """After backward: join the weight-gradient side stream; parameters that received no gradient this step get
+        an explicit zero."""
+        SideStream.join(self.flat.device)
         for e in GradSink.unwritten():
             e.view.zero_()
             GradSink.done(e)
 
     def grad_norm_sq(self):
         """Device scalar sum(g^2) over all parameters (padding is zero)."""
+        SideStream.join(self.flat.device)
         lib = _lib.init(self.flat.device.index)
         ws = _lib.workspace(lib.psg_reduce_workspace_bytes(), self.flat.device)
         check(lib.psg_sumsq_f32(ptr(self.flat), self.numel, ptr(self.normsq), 0, ptr(ws), stream_ptr()), "psg_sumsq_f32")

@@ -97,7 +97,7 @@ class DiffusionStepper:
         eps_hat = self.unet(noisy, t, text_emb)                                                     # :381
         loss, dpred = self.smooth_l1(eps_hat, noise)                                                # :388
         eps_hat.backward(dpred)                                                                     # :396
-        self.arena.finalize()
+        self.arena.finalize()                      # (joins the weight-gradient side stream)
         if self.reducer is not None:
             self.reducer.finish()
             torch.distributed.all_reduce(self.flag, op=torch.distributed.ReduceOp.MAX)              # all ranks skip together
