@@ -68,24 +68,33 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {   // byte offset in
 
 // Fused epilogue for 4 consecutive output channels n..n+3 of tile pixel mt (shared by both kernels):
 //   y = residual + alpha * drop(act(acc + bias + rowadd[b]))   or, with dact_u, the backward form * act'(u)
-template <typename T, int MODE>
-__device__ __forceinline__ void conv_emit(const ConvP& p, int mt, int n, f32x4 v) {
-    int b, m;
+// Tile pixel mt -> row m of y and its sample index b (one decode per PIXEL, shared by its channel groups)
+template <int MODE>
+__device__ __forceinline__ void conv_out_row(const ConvP& p, int mt, int& m, int& b) {
     if (MODE == 3) {                                      // parity class: tile pixel -> row of y
         const int hw = p.sub_nH * p.sub_nW;
         b = mt / hw;
         const int rm = mt - b * hw, i = rm / p.sub_nW, jj = rm - i * p.sub_nW;
         m = (b * p.Ho + p.sub_h0 + 2 * i) * p.Wo + p.sub_w0 + 2 * jj;
     } else {
-        b = mt / (p.Ho * p.Wo);
         m = mt;
+        b = p.rowadd ? mt / (p.Ho * p.Wo) : 0;
     }
+}
+
+// Fused epilogue for 4 consecutive output channels n..n+3 of y row m (sample b):
+//   y = residual + alpha * drop(act(acc + bias + rowadd[b]))   or, with dact_u, the backward form * act'(u)
+// `bias4` and `res4` are loaded by the caller BEFORE any store of the tile: vmcnt retires in order, so a load
+// issued after a store cannot complete before that store has - with the loads inside this function every channel
+// group waited a full store round trip (16 per lane), which made every epilogue with a bias 1.4x slower than one
+// without (fwd vs dgrad of the same GEMM).
+template <typename T>
+__device__ __forceinline__ void conv_emit(const ConvP& p, int m, int b, int n, f32x4 v, f32x4 bias4, f32x4 res4) {
     T* yg = reinterpret_cast<T*>(p.y);
     const T* rag = reinterpret_cast<const T*>(p.rowadd);
-    const T* resg = reinterpret_cast<const T*>(p.residual);
     T* preg = reinterpret_cast<T*>(p.preact);
     const T* dug = reinterpret_cast<const T*>(p.dact_u);
-    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + n);
+    v += bias4;
     if (rag) v += load4<T>(rag + (int64_t)b * p.ldra + n);
     if (preg) store4<T>(preg + (int64_t)m * p.ldpre + n, v);
     if (dug) {          // backward form: multiply by act'(u) of the saved pre-activation
@@ -102,7 +111,7 @@ __device__ __forceinline__ void conv_emit(const ConvP& p, int mt, int n, f32x4 v
             v[e] = drop_keep(p.drop_seed, (uint64_t)m * p.N + n + e, p.drop_thresh) ? v[e] * p.drop_scale : 0.f;
     }
     v *= p.alpha;
-    if (resg) v += load4<T>(resg + (int64_t)m * p.ldres + n);
+    v += res4;
     store4<T>(yg + (int64_t)m * p.ldy + n, v);
 }
 
@@ -339,18 +348,42 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
         __syncthreads();                   // tile kt+1 is in LDS, tile kt no longer needed
     }
 
-    // ---- fused epilogue ------------------------------------------------------
+    // ---- fused epilogue: phase 1 loads every bias / residual operand of the tile, phase 2 computes and stores ----
+    const T* resg = reinterpret_cast<const T*>(p.residual);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     if constexpr (FT16) {
+        int rows[NB], smp[NB];
+        f32x4 bias4[NA];
+        bf16x4 res_raw[NA][NB];
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int n = n0 + wn * WN + i * 16 + 4 * kq;
+            bias4[i] = (p.bias && n < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n) : zero4;
+        }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int mt_ = m0 + wm * WM + j * 16 + l16;
-            if (mt_ >= p.M) continue;
+            rows[j] = -1; smp[j] = 0;
+            if (mt_ < p.M) conv_out_row<MODE>(p, mt_, rows[j], smp[j]);
+            if (resg) {
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    const int n = n0 + wn * WN + i * 16 + 4 * kq;
+                    if (rows[j] >= 0 && n < p.N) res_raw[i][j] = *reinterpret_cast<const bf16x4*>(resg + (int64_t)rows[j] * p.ldres + n);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            if (rows[j] < 0) continue;
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const int n = n0 + wn * WN + i * 16 + 4 * kq;
                 if (n >= p.N) continue;
                 f32x4 v = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                conv_emit<T, MODE>(p, mt_, n, v);
+                f32x4 r4 = zero4;
+                if (resg) { r4[0] = (float)res_raw[i][j][0]; r4[1] = (float)res_raw[i][j][1]; r4[2] = (float)res_raw[i][j][2]; r4[3] = (float)res_raw[i][j][3]; }
+                conv_emit<T>(p, rows[j], smp[j], n, v, bias4[i], r4);
             }
         }
     } else {
@@ -358,14 +391,23 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
         for (int j = 0; j < NB; ++j) {
             const int mt_ = m0 + wm * WM + j * 32 + fr;
             if (mt_ >= p.M) continue;
+            int m, b;
+            conv_out_row<MODE>(p, mt_, m, b);
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
+                f32x4 b4[4], r4[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {          // the 4 channel groups of this 32x32 tile: loads first
+                    const int n = n0 + wn * WN + i * 32 + 8 * g + 4 * fh;
+                    b4[g] = (p.bias && n < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n) : zero4;
+                    r4[g] = (resg && n < p.N) ? load4<T>(resg + (int64_t)m * p.ldres + n) : zero4;
+                }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int n = n0 + wn * WN + i * 32 + 8 * g + 4 * fh;
                     if (n >= p.N) continue;
                     f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                    conv_emit<T, MODE>(p, mt_, n, v);
+                    conv_emit<T>(p, m, b, n, v, b4[g], r4[g]);
                 }
             }
         }
