@@ -84,18 +84,16 @@ __device__ __forceinline__ void conv_out_row(const ConvP& p, int mt, int& m, int
 
 // Fused epilogue for 4 consecutive output channels n..n+3 of y row m (sample b):
 //   y = residual + alpha * drop(act(acc + bias + rowadd[b]))   or, with dact_u, the backward form * act'(u)
-// `bias4` and `res4` are loaded by the caller BEFORE any store of the tile: vmcnt retires in order, so a load
+// `bias4`, `ra4` (per-sample add) and `res4` are loaded by the caller BEFORE the stores they would otherwise trail: vmcnt retires in order, so a load
 // issued after a store cannot complete before that store has - with the loads inside this function every channel
 // group waited a full store round trip (16 per lane), which made every epilogue with a bias 1.4x slower than one
 // without (fwd vs dgrad of the same GEMM).
 template <typename T>
-__device__ __forceinline__ void conv_emit(const ConvP& p, int m, int b, int n, f32x4 v, f32x4 bias4, f32x4 res4) {
+__device__ __forceinline__ void conv_emit(const ConvP& p, int m, int n, f32x4 v, f32x4 bias4, f32x4 ra4, f32x4 res4) {
     T* yg = reinterpret_cast<T*>(p.y);
-    const T* rag = reinterpret_cast<const T*>(p.rowadd);
     T* preg = reinterpret_cast<T*>(p.preact);
     const T* dug = reinterpret_cast<const T*>(p.dact_u);
-    v += bias4;
-    if (rag) v += load4<T>(rag + (int64_t)b * p.ldra + n);
+    v += bias4 + ra4;
     if (preg) store4<T>(preg + (int64_t)m * p.ldpre + n, v);
     if (dug) {          // backward form: multiply by act'(u) of the saved pre-activation
         const f32x4 u = load4<T>(dug + (int64_t)m * p.lddact + n);
@@ -350,6 +348,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
 
     // ---- fused epilogue: phase 1 loads every bias / residual operand of the tile, phase 2 computes and stores ----
     const T* resg = reinterpret_cast<const T*>(p.residual);
+    const T* rag = reinterpret_cast<const T*>(p.rowadd);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     if constexpr (FT16) {
         int rows[NB], smp[NB];
@@ -376,6 +375,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             if (rows[j] < 0) continue;
+            f32x4 ra4[NA];                                 // per-sample add of this pixel's sample: loads before its stores
+#pragma unroll
+            for (int i = 0; i < NA; ++i) {
+                const int n = n0 + wn * WN + i * 16 + 4 * kq;
+                ra4[i] = (rag && n < p.N) ? load4<T>(rag + (int64_t)smp[j] * p.ldra + n) : zero4;
+            }
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
                 const int n = n0 + wn * WN + i * 16 + 4 * kq;
@@ -383,7 +388,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
                 f32x4 v = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                 f32x4 r4 = zero4;
                 if (resg) { r4[0] = (float)res_raw[i][j][0]; r4[1] = (float)res_raw[i][j][1]; r4[2] = (float)res_raw[i][j][2]; r4[3] = (float)res_raw[i][j][3]; }
-                conv_emit<T>(p, rows[j], smp[j], n, v, bias4[i], r4);
+                conv_emit<T>(p, rows[j], n, v, bias4[i], ra4[i], r4);
             }
         }
     } else {
@@ -395,19 +400,20 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
             conv_out_row<MODE>(p, mt_, m, b);
 #pragma unroll
             for (int i = 0; i < NA; ++i) {
-                f32x4 b4[4], r4[4];
+                f32x4 b4[4], r4[4], a4[4];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {          // the 4 channel groups of this 32x32 tile: loads first
                     const int n = n0 + wn * WN + i * 32 + 8 * g + 4 * fh;
                     b4[g] = (p.bias && n < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n) : zero4;
                     r4[g] = (resg && n < p.N) ? load4<T>(resg + (int64_t)m * p.ldres + n) : zero4;
+                    a4[g] = (rag && n < p.N) ? load4<T>(rag + (int64_t)b * p.ldra + n) : zero4;
                 }
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int n = n0 + wn * WN + i * 32 + 8 * g + 4 * fh;
                     if (n >= p.N) continue;
                     f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                    conv_emit<T>(p, m, b, n, v, b4[g], r4[g]);
+                    conv_emit<T>(p, m, n, v, b4[g], a4[g], r4[g]);
                 }
             }
         }
