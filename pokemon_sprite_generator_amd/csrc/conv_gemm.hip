@@ -335,25 +335,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
 
     const int KT = p.KT;
     load_tiles(0, 0);
-    wait_vmcnt<0>();
-    __syncthreads();                       // the DMA of tile 0 has landed for every wave
-    for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
-        // buffer buf^1 was last read in step kt-1, which every wave finished before the barrier below
-        if (kt + 1 < KT) load_tiles(kt + 1, buf ^ 1);
-        compute(buf);
-        wait_vmcnt<0>();                   // (asm LDS-DMA is invisible to hipcc: the wait is ours)
-        __syncthreads();                   // tile kt+1 is in LDS, tile kt no longer needed
-    }
-
-    // ---- fused epilogue: phase 1 loads every bias / residual operand of the tile, phase 2 computes and stores ----
+    // Epilogue operands that do not depend on the GEMM (bias, residual, output-row decode) are requested NOW, right
+    // behind the first tile's DMA: their latency disappears under the K loop instead of being exposed after it.
+    // (A residual that aliases y is still read before this workgroup - the only writer of these rows - stores.)
     const T* resg = reinterpret_cast<const T*>(p.residual);
     const T* rag = reinterpret_cast<const T*>(p.rowadd);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    int rows[FT16 ? NB : 1], smp[FT16 ? NB : 1];
+    f32x4 bias4[FT16 ? NA : 1];
+    bf16x4 res_raw[FT16 ? NA : 1][FT16 ? NB : 1];
     if constexpr (FT16) {
-        int rows[NB], smp[NB];
-        f32x4 bias4[NA];
-        bf16x4 res_raw[NA][NB];
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
             const int n = n0 + wn * WN + i * 16 + 4 * kq;
@@ -372,6 +363,20 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
                 }
             }
         }
+    }
+    wait_vmcnt<0>();
+    __syncthreads();                       // the DMA of tile 0 has landed for every wave
+    for (int kt = 0; kt < KT; ++kt) {
+        const int buf = kt & 1;
+        // buffer buf^1 was last read in step kt-1, which every wave finished before the barrier below
+        if (kt + 1 < KT) load_tiles(kt + 1, buf ^ 1);
+        compute(buf);
+        wait_vmcnt<0>();                   // (asm LDS-DMA is invisible to hipcc: the wait is ours)
+        __syncthreads();                   // tile kt+1 is in LDS, tile kt no longer needed
+    }
+
+    // ---- fused epilogue: phase 1 loads every bias / residual operand of the tile, phase 2 computes and stores ----
+    if constexpr (FT16) {
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             if (rows[j] < 0) continue;
