@@ -247,6 +247,29 @@ def test_conv_fwd_dgrad_wgrad(psg, dtype, B, H, Cin, Cout, ks, stride):
     assert maxrel(from_cl(resd.grad.cpu()), res.grad) < tol, "d residual"
 
 
+@pytest.mark.parametrize("B,H,Cin,Cout", [(256, 14, 64, 128), (512, 7, 128, 128), (72, 27, 64, 256), (2048, 4, 64, 128)])
+def test_conv3x3_large_tiles(psg, B, H, Cin, Cout):
+    """Shapes large enough for the tile chooser to pick the 128x128 / 128x160 tiles the benchmark runs on (the small
+    parity cases above mostly take 64x64): bf16 forward and data gradient against a CPU fp32 convolution of the same
+    bf16 operands, for every map width of the U-Net (27, 14, 7, 4)."""
+    from pokemon_sprite_generator_amd import ops
+    dtype = torch.bfloat16
+    name = f"halo{B}.{H}.{Cin}.{Cout}"
+    x = _q(h((B, Cin, H, H), name + "x", 1.2), dtype).requires_grad_(True)
+    w = _q(h((Cout, Cin, 3, 3), name + "w", math.sqrt(3.0 / (Cin * 9))), dtype).requires_grad_(True)
+    b = h((Cout,), name + "b", 0.2)
+    ref = F.conv2d(x, w, b, padding=1)
+    gy = _q(h(tuple(ref.shape), name + "gy", 1.0), dtype)
+    ref.backward(gy)
+    xd = to_cl(x.detach(), dtype).to(DEV).requires_grad_(True)
+    wd = w.detach().to(DEV)
+    y = ops.conv2d(xd, wd, b.to(DEV))
+    y.backward(to_cl(gy, dtype).to(DEV))
+    tol = TOL[dtype]
+    assert maxrel(from_cl(y.cpu()), ref.detach()) < tol, "forward"
+    assert maxrel(from_cl(xd.grad.cpu()), x.grad) < tol, "dgrad"
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("B,H,Cin,Cout,stride,uses", [(2, 9, 64, 96, 1, 1), (3, 14, 160, 320, 2, 1), (40, 27, 32, 64, 1, 2)])
 def test_conv_ohwi_master_weights(psg, dtype, B, H, Cin, Cout, stride, uses):
