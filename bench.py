@@ -202,12 +202,12 @@ def main():
             # memory-side bytes per launch come from a SEPARATE rocprofv3 --pmc pass of this same command (PMC cannot
             # be read from inside the process); the committed summary is attached when it covers the workload
             traffic, traffic_src = None, None
-            tpath = os.path.join(ROOT, "profiles", "r01_c_pmc_traffic.json")
+            tpath = os.path.join(ROOT, "profiles", "r01_e_pmc_traffic.json")
             if B == 256 and args.dtype == "bf16" and os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
                     traffic = tj["families"][dom["kernel"]]["traffic_bytes_per_launch"]
-                    traffic_src = "profiles/r01_c_pmc_traffic.json: " + tj["correction"]
+                    traffic_src = "profiles/r01_e_pmc_traffic.json: " + tj["correction"]
                 except Exception:                    # noqa: BLE001
                     traffic = None
             res["roofline"] = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],

@@ -38,13 +38,7 @@ struct ConvP {
     int tap_dh[4], tap_dw[4], tap_wi[4];
 };
 
-template <typename T> struct Mma;
-template <> struct Mma<bf16_t> {
-    static __device__ __forceinline__ f32x16 run(const uint4& a, const uint4& b, f32x16 c) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a),
-                                                       *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
-    }
-};
+template <typename T> struct Mma;           // 32x32 fragment path (fp32 only; bf16 uses mma16 below)
 template <> struct Mma<float> {
     static __device__ __forceinline__ f32x16 run(const uint4& a, const uint4& b, f32x16 c) {
         const float* fa = reinterpret_cast<const float*>(&a);

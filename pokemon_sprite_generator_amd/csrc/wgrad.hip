@@ -3,16 +3,19 @@
 //   dW[co, q] = sum_m dY[m, co] * X[pix(m, tap(q)), ci(q)],   q = tap*Cin + ci
 //
 // Both operands are stored with the REDUCTION index (pixel m) as the slow
-// dimension (channels-last), i.e. this is a "TN" GEMM.  Tiles [pixels][128 ch]
-// of dY and of the gathered X are register-staged into LDS as they lie in
-// memory; the MFMA fragments (which need 8 consecutive reduction indices per
-// lane) are produced by the hardware transposing LDS read ds_read_b64_tr_b16
-// (bf16; row stride 320 B makes the 4x16 blocks of a half-wave hit 64 distinct
-// banks) or by plain ds_read_b32 (fp32 v_mfma_f32_32x32x2_f32 takes one value
-// per lane).  Output tile 128(co) x 128(q) per 256-thread workgroup, columns
-// tiled over the flat q axis (so Cin=320 wastes nothing), split-K over pixels
-// with fp32 partial slabs and a deterministic reduce+permute pass that writes
-// the OIHW fp32 gradient.
+// dimension (channels-last), i.e. this is a "TN" GEMM.  Tiles [64 pixels][128 ch]
+// of dY and of the gathered X go global -> LDS by LDS-DMA (inline-asm
+// buffer_load ... lds, hand-placed waits) exactly as they lie in memory; the MFMA
+// fragments (which need 8 consecutive reduction indices per lane) are produced by
+// the hardware transposing LDS read ds_read_b64_tr_b16 (bf16: 256-byte rows, chunk
+// XOR ((row&3)<<2)|((row>>2)&3) applied on the DMA source side makes the reads of
+// the 16x16x32 operand conflict-free) or by plain ds_read_b32 (fp32
+// v_mfma_f32_32x32x2_f32 takes one value per lane).  Output tile 128(co) x 128(q)
+// per 256-thread workgroup, columns tiled over the flat q axis (so Cin=320 wastes
+// nothing), split-K over pixels chosen by a makespan model, fp32 partial slabs and
+// a deterministic fixed-order sum that writes the gradient in the parameter's own
+// memory order (OHWI: no permute; one split: tiles written directly); the bias
+// gradient rides along as one extra MFMA per dY fragment against a ones operand.
 #include "psg_common.h"
 
 namespace psg {
