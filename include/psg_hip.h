@@ -163,7 +163,9 @@ typedef struct psg_conv_desc {
     const void* residual;        /* [M, Cout] or NULL; may alias y (accumulate) */
     void* preact;                /* optional store of (acc+bias+rowadd) for backward, or NULL */
     const void* dact_u;          /* backward form: when non-NULL, `act` is NOT applied; the value is multiplied by
-                                    act'(dact_u[m,n]) (saved pre-activation) and by the same dropout mask */
+                                    act'(dact_u[m,n]) (saved pre-activation) and by the same dropout mask.  Used by
+                                    the FFN backward: the data gradient of its second Linear comes out already
+                                    multiplied by GELU'(u) * mask of the first.  Mutually exclusive with residual. */
 } psg_conv_desc;
 int psg_conv_fwd(const psg_conv_desc* d, psg_stream_t stream);
 

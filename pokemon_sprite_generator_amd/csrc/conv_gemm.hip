@@ -83,16 +83,15 @@ __device__ __forceinline__ void conv_out_row(const ConvP& p, int mt, int& m, int
 // group waited a full store round trip (16 per lane), which made every epilogue with a bias 1.4x slower than one
 // without (fwd vs dgrad of the same GEMM).
 template <typename T>
-__device__ __forceinline__ void conv_emit(const ConvP& p, int m, int n, f32x4 v, f32x4 bias4, f32x4 ra4, f32x4 res4) {
+__device__ __forceinline__ void conv_emit(const ConvP& p, int m, int n, f32x4 v, f32x4 bias4, f32x4 ra4, f32x4 aux4) {
+    // aux4: the residual, or (backward form, dact_u set - the two are mutually exclusive) the saved pre-activation u
     T* yg = reinterpret_cast<T*>(p.y);
     T* preg = reinterpret_cast<T*>(p.preact);
-    const T* dug = reinterpret_cast<const T*>(p.dact_u);
     v += bias4 + ra4;
     if (preg) store4<T>(preg + (int64_t)m * p.ldpre + n, v);
-    if (dug) {          // backward form: multiply by act'(u) of the saved pre-activation
-        const f32x4 u = load4<T>(dug + (int64_t)m * p.lddact + n);
+    if (p.dact_u) {     // backward form: multiply by act'(u) of the saved pre-activation
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= act_grad(u[e], p.act);
+        for (int e = 0; e < 4; ++e) v[e] *= act_grad(aux4[e], p.act);
     } else if (p.act != PSG_ACT_NONE) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = act_f(v[e], p.act);
@@ -103,7 +102,7 @@ __device__ __forceinline__ void conv_emit(const ConvP& p, int m, int n, f32x4 v,
             v[e] = drop_keep(p.drop_seed, (uint64_t)m * p.N + n + e, p.drop_thresh) ? v[e] * p.drop_scale : 0.f;
     }
     v *= p.alpha;
-    v += res4;
+    if (!p.dact_u) v += aux4;
     store4<T>(yg + (int64_t)m * p.ldy + n, v);
 }
 
@@ -332,7 +331,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
     // Epilogue operands that do not depend on the GEMM (bias, residual, output-row decode) are requested NOW, right
     // behind the first tile's DMA: their latency disappears under the K loop instead of being exposed after it.
     // (A residual that aliases y is still read before this workgroup - the only writer of these rows - stores.)
-    const T* resg = reinterpret_cast<const T*>(p.residual);
+    // (aux operand of the epilogue: the residual, or the saved pre-activation of the backward form)
+    const T* resg = reinterpret_cast<const T*>(p.dact_u ? p.dact_u : p.residual);
+    const int64_t ldaux = p.dact_u ? p.lddact : p.ldres;
     const T* rag = reinterpret_cast<const T*>(p.rowadd);
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     int rows[FT16 ? NB : 1], smp[FT16 ? NB : 1];
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
 #pragma unroll
                 for (int i = 0; i < NA; ++i) {
                     const int n = n0 + wn * WN + i * 16 + 4 * kq;
-                    if (rows[j] >= 0 && n < p.N) res_raw[i][j] = *reinterpret_cast<const bf16x4*>(resg + (int64_t)rows[j] * p.ldres + n);
+                    if (rows[j] >= 0 && n < p.N) res_raw[i][j] = *reinterpret_cast<const bf16x4*>(resg + (int64_t)rows[j] * ldaux + n);
                 }
             }
         }
@@ -404,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
                 for (int g = 0; g < 4; ++g) {          // the 4 channel groups of this 32x32 tile: loads first
                     const int n = n0 + wn * WN + i * 32 + 8 * g + 4 * fh;
                     b4[g] = (p.bias && n < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n) : zero4;
-                    r4[g] = (resg && n < p.N) ? load4<T>(resg + (int64_t)m * p.ldres + n) : zero4;
+                    r4[g] = (resg && n < p.N) ? load4<T>(resg + (int64_t)m * ldaux + n) : zero4;
                     a4[g] = (rag && n < p.N) ? load4<T>(rag + (int64_t)b * p.ldra + n) : zero4;
                 }
 #pragma unroll
@@ -519,6 +520,7 @@ int psg_conv_fwd(const psg_conv_desc* d, psg_stream_t stream) {
     PSG_REQUIRE(!d->preact || (aligned16(d->preact) && d->ld_preact % 4 == 0), PSG_ERR_ALIGN, "conv_fwd: preact alignment");
     PSG_REQUIRE(!d->dact_u || (aligned16(d->dact_u) && d->ld_dact % 4 == 0), PSG_ERR_ALIGN, "conv_fwd: dact_u alignment");
     PSG_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, PSG_ERR_ARG, "conv_fwd: drop_p %f", d->drop_p);
+    PSG_REQUIRE(!(d->residual && d->dact_u), PSG_ERR_ARG, "conv_fwd: residual and dact_u are mutually exclusive");
     // geometry consistency
     if (!d->transposed) {
         PSG_REQUIRE(d->Ho == (d->Hi + 2 * d->pad - d->ksize) / d->stride + 1 && d->Wo == (d->Wi + 2 * d->pad - d->ksize) / d->stride + 1,

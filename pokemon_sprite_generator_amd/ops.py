@@ -407,6 +407,87 @@ def linear(x, weight, bias=None, residual=None, act=ACT_NONE, alpha=1.0, drop_p=
     return _ConvFn.apply(x, weight, bias, None, residual, 1, act, alpha, drop_p, seed)
 
 
+class _FFNFn(torch.autograd.Function):
+    """y = x + alpha * drop2(W2 . drop1(gelu(W1 x + b1)) + b2)   - the FFN of CrossAttentionBlock (unet.py:176-187, 250).
+
+    One node instead of two `_ConvFn`s so that backward can use the kernels' fused forms: the data gradient of the
+    second Linear is produced ALREADY multiplied by GELU'(u) and the first dropout mask (psg_conv_fwd's dact_u
+    form: no pass over the [M, hidden] gradient), and the residual branch's gradient is added in the epilogue of the
+    first Linear's data gradient (no autograd add)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, alpha, drop_p, seed1, seed2):
+        lib = _lib_for(x)
+        dtype = x.dtype
+        C, Hd = w1.shape[1], w1.shape[0]
+        xr, ldx = _rows(x)
+        M = xr.numel() // C
+        need = any(ctx.needs_input_grad)
+        wf1, wd1 = WeightCache.get(w1, dtype, need)
+        wf2, wd2 = WeightCache.get(w2, dtype, need)
+        u = torch.empty((M, Hd), dtype=dtype, device=x.device) if need else None
+        hmid = torch.empty((M, Hd), dtype=dtype, device=x.device)
+        y = torch.empty(x.shape, dtype=dtype, device=x.device)
+        g1 = (M, 1, 1, 1, 1, 1, 1, 0)
+        _conv_launch(lib, dtype, xr, ldx, wf1, 0, hmid, Hd, g1, C, Hd, bias=b1, preact=u, act=ACT_GELU, drop_p=drop_p, seed=seed1)
+        _conv_launch(lib, dtype, hmid, Hd, wf2, 0, y, C, g1, Hd, C, bias=b2, residual=xr, ld_res=ldx, alpha=alpha, drop_p=drop_p, seed=seed2)
+        ctx.save_for_backward(xr, u, hmid, w1, w2)
+        ctx.params = (w1, b1, w2, b2)
+        ctx.meta = (M, C, Hd, ldx, alpha, drop_p, seed1, seed2, tuple(x.shape), wd1, wd2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        xr, u, hmid, w1, w2 = ctx.saved_tensors
+        w1p, b1p, w2p, b2p = ctx.params
+        M, C, Hd, ldx, alpha, drop_p, seed1, seed2, x_shape, wd1, wd2 = ctx.meta
+        lib = _lib_for(dy)
+        dtype = dy.dtype
+        dyr, lddy = _rows(dy)
+        geo = (M, 1, 1, 1, 1, 1, 1, 0)
+        if wd1 is None:
+            _, wd1 = WeightCache.get(w1, dtype, True)
+        if wd2 is None:
+            _, wd2 = WeightCache.get(w2, dtype, True)
+        # gradient w.r.t. the second Linear's accumulator (dropout 2 and the 0.6 gate)
+        g2 = torch.empty((M, C), dtype=dtype, device=dy.device)
+        check(lib.psg_epilogue_bwd(ptr(dyr), lddy, None, C, ptr(g2), C, M, C, ACT_NONE, float(alpha), float(drop_p), int(seed2),
+                                   dtype_code(dtype), stream_ptr()), "psg_epilogue_bwd")
+        # d/du of the first Linear's pre-activation: dgrad of Linear 2 with the backward-form epilogue
+        gu = torch.empty((M, Hd), dtype=dtype, device=dy.device)
+        _conv_launch(lib, dtype, g2, C, wd2, 0, gu, Hd, geo, C, Hd, transposed=True, dact_u=u, ld_dact=Hd, act=ACT_GELU, drop_p=drop_p, seed=seed1)
+
+        def wgrad(xin, ldxin, g, ldg, wp, bp, cin, cout):
+            wo, wacc, we = _param_out(wp)
+            bo, bacc, be = _param_out(bp)
+            if SideStream.enabled and we is not None:
+                side, cur = SideStream.get(dy.device), torch.cuda.current_stream(dy.device)
+                side.wait_stream(cur)
+                with torch.cuda.stream(side):
+                    _wgrad_launch(lib, dtype, xin, ldxin, g, ldg, wo, geo, cin, cout, accumulate=wacc, dbias=bo, accumulate_bias=bacc)
+                g.record_stream(side); xin.record_stream(side)
+                SideStream.used = True
+            else:
+                _wgrad_launch(lib, dtype, xin, ldxin, g, ldg, wo, geo, cin, cout, accumulate=wacc, dbias=bo, accumulate_bias=bacc)
+            return _param_ret(wo, we), _param_ret(bo, be)
+
+        dw2 = db2 = dw1 = db1 = dx = None
+        if ctx.needs_input_grad[3] or ctx.needs_input_grad[4]:
+            dw2, db2 = wgrad(hmid, Hd, g2, C, w2p, b2p, Hd, C)
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty(x_shape, dtype=dtype, device=dy.device)
+            # dx = W1^T gu + dy (the residual branch's gradient rides in the epilogue)
+            _conv_launch(lib, dtype, gu, Hd, wd1, 0, dx, C, geo, Hd, C, transposed=True, residual=dyr, ld_res=lddy)
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dw1, db1 = wgrad(xr, ldx, gu, Hd, w1p, b1p, C, Hd)
+        return dx, dw1, db1, dw2, db2, None, None, None, None
+
+
+def ffn(x, w1, b1, w2, b2, alpha, drop_p=0.0, seed1=0, seed2=0):
+    """x + alpha * drop(W2 drop(gelu(W1 x + b1)) + b2), fused forward epilogues and backward forms (see _FFNFn)."""
+    return _FFNFn.apply(x, w1, b1, w2, b2, alpha, drop_p, seed1, seed2)
+
+
 class _CrossInProjFn(torch.autograd.Function):
     """Packed MHA in-projection for cross-attention (unet.py:235 -> F.multi_head_attention_forward):
     q = xn @ W[:E]^T + b[:E];  kv = tp @ W[E:]^T + b[E:]  with ONE packed parameter [3E, E]."""

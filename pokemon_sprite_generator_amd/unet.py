@@ -13,11 +13,15 @@ statistics, softmax, accumulators, parameters and their gradients stay fp32.
 """
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 
 from . import ops
 from .ops import ACT_GELU, ACT_NONE, ACT_SILU
+
+_FUSED_FFN = os.environ.get("PSG_FFN_FUSE", "1") != "0"
 
 ATTN_DROPOUT = 0.05   # nn.MultiheadAttention(dropout=0.05), nn.Dropout(0.05): unet.py:160-187
 
@@ -151,8 +155,11 @@ class CrossAttentionBlock(nn.Module):
         o = ops.attention_cross(q, kv, self.num_heads, p, seeds[1])
         tok = ops.linear(o, ca.out_proj.weight, ca.out_proj.bias, residual=tok, alpha=0.8)
         # feed-forward, no norm (unet.py:247-251)
-        h = ops.linear(tok, self.ffn[0].weight, self.ffn[0].bias, act=ACT_GELU, drop_p=p, seed=seeds[2])
-        tok = ops.linear(h, self.ffn[3].weight, self.ffn[3].bias, residual=tok, alpha=0.6, drop_p=p, seed=seeds[3])
+        if _FUSED_FFN:
+            tok = ops.ffn(tok, self.ffn[0].weight, self.ffn[0].bias, self.ffn[3].weight, self.ffn[3].bias, 0.6, p, seeds[2], seeds[3])
+        else:                                          # two generic nodes (PSG_FFN_FUSE=0: A/B and debugging)
+            h = ops.linear(tok, self.ffn[0].weight, self.ffn[0].bias, act=ACT_GELU, drop_p=p, seed=seeds[2])
+            tok = ops.linear(h, self.ffn[3].weight, self.ffn[3].bias, residual=tok, alpha=0.6, drop_p=p, seed=seeds[3])
         return tok.reshape(B, H, W, C)
 
     def forward(self, x: torch.Tensor, text_emb: torch.Tensor) -> torch.Tensor:
