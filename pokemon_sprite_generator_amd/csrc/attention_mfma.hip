@@ -18,7 +18,8 @@
 // log-sum-exp: the dQ kernel has the same query-on-lane structure (dS^T is directly the B
 // operand of dQ^T += K^T . dS^T); the dK/dV kernel puts the KEY on the lane so that P and dS
 // are directly the B operands of dV^T += dO^T . P and dK^T += Q^T . dS.
-// Dropout uses the same stateless hash as the fp32 path (attn_idx), so masks agree in fwd/bwd.
+// Dropout: a stateless 16-bit-per-element hash shared by the two keys of a pair (psg_common.h: drop_hash_pair),
+// regenerated identically in both backward kernels.
 #include "psg_common.h"
 
 namespace psg {
@@ -153,10 +154,13 @@ __global__ __launch_bounds__(256, (ND <= 5 ? 2 : 1)) void attn_fwd_mfma(const At
             lsum = lsum * alpha + ps;
             m = mn;
             if (p.drop_thresh) {
+                const uint64_t prow = ((uint64_t)bh * p.L + l) * (uint64_t)((p.S + 1) >> 1);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                for (int r = 0; r < 16; r += 2) {          // registers r, r+1 hold keys 2k, 2k+1: one hash for both
                     const int key = kt * 32 + acc_row(r, fh);
-                    st[r] = (lok && key < p.S && drop_keep(p.seed, ((uint64_t)bh * p.L + l) * p.S + key, p.drop_thresh)) ? st[r] * p.drop_scale : 0.f;
+                    const uint32_t hh = drop_hash_pair(p.seed, prow + (uint32_t)(key >> 1));
+                    st[r] = (lok && key < p.S && drop_keep_half(hh, 0, p.drop_thresh)) ? st[r] * p.drop_scale : 0.f;
+                    st[r + 1] = (lok && key + 1 < p.S && drop_keep_half(hh, 1, p.drop_thresh)) ? st[r + 1] * p.drop_scale : 0.f;
                 }
             }
 #pragma unroll
@@ -259,6 +263,7 @@ __global__ __launch_bounds__(256, (ND <= 5 ? 2 : 1)) void attn_dq_mfma(const Att
                 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, gf[ks], dp, 0, 0, 0);
             }
+            const uint64_t prow = ((uint64_t)bh * p.L + l) * (uint64_t)((p.S + 1) >> 1);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kt * 32 + acc_row(r, fh);
@@ -266,7 +271,10 @@ __global__ __launch_bounds__(256, (ND <= 5 ? 2 : 1)) void attn_dq_mfma(const Att
                 if (lok && key < p.S) {
                     const float pr = __expf(st[r] * p.scale - lse);
                     float dpr = dp[r];
-                    if (p.drop_thresh) dpr = drop_keep(p.seed, ((uint64_t)bh * p.L + l) * p.S + key, p.drop_thresh) ? dpr * p.drop_scale : 0.f;
+                    if (p.drop_thresh) {               // (the two registers of a key pair compute the same hash: CSE'd)
+                        const uint32_t hh = drop_hash_pair(p.seed, prow + (uint32_t)(key >> 1));
+                        dpr = drop_keep_half(hh, key & 1, p.drop_thresh) ? dpr * p.drop_scale : 0.f;
+                    }
                     ds = pr * (dpr - del) * p.scale;
                 }
                 st[r] = ds;
@@ -389,7 +397,8 @@ __global__ __launch_bounds__(256, (ND <= 5 ? 2 : 1)) void attn_dkv_mfma(const At
                     float dpr = dp[r];
                     pv = pr;
                     if (p.drop_thresh) {
-                        const bool keep = drop_keep(p.seed, ((uint64_t)bh * p.L + l) * p.S + key, p.drop_thresh);
+                        const uint32_t hh = drop_hash_pair(p.seed, ((uint64_t)bh * p.L + l) * (uint64_t)((p.S + 1) >> 1) + (uint32_t)(key >> 1));
+                        const bool keep = drop_keep_half(hh, key & 1, p.drop_thresh);
                         pv = keep ? pr * p.drop_scale : 0.f;
                         dpr = keep ? dpr * p.drop_scale : 0.f;
                     }

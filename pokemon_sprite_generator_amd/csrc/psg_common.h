@@ -109,6 +109,16 @@ __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t 
     h = mix32(h ^ (hi * 0x85EBCA77u + (uint32_t)(seed >> 32)));
     return h >= thresh;
 }
+// Attention probabilities (MFMA kernels): ONE 32-bit hash serves the two keys 2k, 2k+1 of a query row (16 bits
+// each, resolution 1/65536) - the per-element hash was the largest VALU cost of the train-mode attention kernels.
+// pair = row * ceil(S/2) + (key >> 1); the same function regenerates the mask in both backward kernels.
+__device__ __forceinline__ uint32_t drop_hash_pair(uint64_t seed, uint64_t pair) {
+    const uint32_t lo = (uint32_t)pair, hi = (uint32_t)(pair >> 32);
+    return mix32(lo * 0x9E3779B1u + (uint32_t)seed + ((hi * 0x85EBCA77u) ^ (uint32_t)(seed >> 32)));
+}
+__device__ __forceinline__ bool drop_keep_half(uint32_t h, int odd, uint32_t thresh) {
+    return ((odd ? (h >> 16) : (h & 0xFFFFu)) >= (thresh >> 16));
+}
 static inline uint32_t drop_thresh(float p) {
     double t = (double)p * 4294967296.0;
     if (t < 0) t = 0;

@@ -15,11 +15,11 @@ for H, L, S, d, self_mode in cases:
     E = H * d
     if self_mode:
         q = torch.randn(B, L, 3 * E, device='cuda').bfloat16().requires_grad_(True); kv = None
-        f = lambda: ops.attention_self(q, H)
+        f = lambda: ops.attention_self(q, H, 0.05, 123)
     else:
         q = torch.randn(B, L, E, device='cuda').bfloat16().requires_grad_(True)
         kv = torch.randn(B, S, 2 * E, device='cuda').bfloat16().requires_grad_(True)
-        f = lambda: ops.attention_cross(q, kv, H)
+        f = lambda: ops.attention_cross(q, kv, H, 0.05, 123)
     o = f(); g = torch.randn_like(o)
     with torch.no_grad(): t1 = timeit(f)
     ins = (q,) if self_mode else (q, kv)
