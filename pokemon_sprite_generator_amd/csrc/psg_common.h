@@ -98,20 +98,13 @@ __device__ __forceinline__ float act_grad(float x, int act) {
 }
 
 // ---- stateless dropout mask ---------------------------------------------------
-// keep(idx) = hash(seed, idx) >= p * 2^32 ; the same function regenerates the mask in backward.
+// keep(idx) = 16-bit half of hash(seed, idx >> 1) >= p * 2^16 ; the same function regenerates the mask in backward.
 __device__ __forceinline__ uint32_t mix32(uint32_t h) {
     h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;
     return h;
 }
-__device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
-    uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
-    uint32_t h = mix32(lo * 0x9E3779B1u + (uint32_t)seed);
-    h = mix32(h ^ (hi * 0x85EBCA77u + (uint32_t)(seed >> 32)));
-    return h >= thresh;
-}
-// Attention probabilities (MFMA kernels): ONE 32-bit hash serves the two keys 2k, 2k+1 of a query row (16 bits
-// each, resolution 1/65536) - the per-element hash was the largest VALU cost of the train-mode attention kernels.
-// pair = row * ceil(S/2) + (key >> 1); the same function regenerates the mask in both backward kernels.
+// One 32-bit hash serves the two elements 2k, 2k+1 (16 bits each, resolution 1/65536): half the hash rounds of a
+// per-element hash, and adjacent elements of a lane (vector epilogues, key pairs of an attention row) share it.
 __device__ __forceinline__ uint32_t drop_hash_pair(uint64_t seed, uint64_t pair) {
     const uint32_t lo = (uint32_t)pair, hi = (uint32_t)(pair >> 32);
     return mix32(lo * 0x9E3779B1u + (uint32_t)seed + ((hi * 0x85EBCA77u) ^ (uint32_t)(seed >> 32)));
@@ -119,6 +112,10 @@ __device__ __forceinline__ uint32_t drop_hash_pair(uint64_t seed, uint64_t pair)
 __device__ __forceinline__ bool drop_keep_half(uint32_t h, int odd, uint32_t thresh) {
     return ((odd ? (h >> 16) : (h & 0xFFFFu)) >= (thresh >> 16));
 }
+__device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
+    return drop_keep_half(drop_hash_pair(seed, idx >> 1), (int)(idx & 1), thresh);
+}
+// (attention_mfma.hip pairs the keys 2k, 2k+1 of a query row: pair = row * ceil(S/2) + (key >> 1))
 static inline uint32_t drop_thresh(float p) {
     double t = (double)p * 4294967296.0;
     if (t < 0) t = 0;
