@@ -457,13 +457,13 @@ static int choose_and_launch(const ConvP& p, int dtype, hipStream_t s) {
     {
         static int force = -2;                             // PSG_CONV_TILE=0..3 pins a candidate (kernel A/B runs)
         if (force == -2) { const char* e = getenv("PSG_CONV_TILE"); force = e ? atoi(e) : -1; }
-        const int cand[4][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 160}};
-        double eff[4] = {1.0, 0.78, 0.55, 1.0};            // measured relative MFMA efficiency of the tile shapes
+        const int cand[5][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 160}, {64, 160}};
+        double eff[5] = {1.0, 0.78, 0.55, 1.0, 0.80};      // measured relative MFMA efficiency of the tile shapes
         if (p.KT <= 10) eff[1] = 1.1;                      // K <= 640: 3 resident 128x64 workgroups hide the short K loop's ends
-        if (dtype != PSG_BF16) eff[3] = 0.0;               // 160 = 2 x 5 x 16: only the 16x16x32 bf16 tiles divide it
+        if (dtype != PSG_BF16) eff[3] = eff[4] = 0.0;      // 160 = 2 x 5 x 16: only the 16x16x32 bf16 tiles divide it
         const double slots = 512.0;                        // resident workgroups on the chip (2 per CU)
         double best = -1.0;
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < 5; ++c) {
             const double tiles = (double)((M + cand[c][0] - 1) / cand[c][0]) * (double)((p.N + cand[c][1] - 1) / cand[c][1]);
             const double useful = (double)M * p.N / (tiles * cand[c][0] * cand[c][1]);
             const double waves = ceil(tiles / slots);
@@ -472,6 +472,7 @@ static int choose_and_launch(const ConvP& p, int dtype, hipStream_t s) {
             if (score > best) { best = score; BM = cand[c][0]; BN = cand[c][1]; }
         }
     }
+    if (BN == 160 && BM == 64) return launch_conv<bf16_t, 64, 160>(p, s);
     if (BN == 160) return launch_conv<bf16_t, 128, 160>(p, s);
     if (dtype == PSG_F32) {
         if (BM == 128 && BN == 128) return launch_conv<float, 128, 128>(p, s);
@@ -498,6 +499,7 @@ int psg_conv_init_attrs(void) {
     if ((rc = set_conv_attrs<float, 64, 64>())) return rc;
     if ((rc = set_conv_attrs<bf16_t, 64, 64>())) return rc;
     if ((rc = set_conv_attrs<bf16_t, 128, 160>())) return rc;
+    if ((rc = set_conv_attrs<bf16_t, 64, 160>())) return rc;
     return PSG_OK;
 }
 
