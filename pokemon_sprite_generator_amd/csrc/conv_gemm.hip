@@ -458,7 +458,7 @@ static int choose_and_launch(const ConvP& p, int dtype, hipStream_t s) {
         static int force = -2;                             // PSG_CONV_TILE=0..3 pins a candidate (kernel A/B runs)
         if (force == -2) { const char* e = getenv("PSG_CONV_TILE"); force = e ? atoi(e) : -1; }
         const int cand[5][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 160}, {64, 160}};
-        double eff[5] = {1.0, 0.78, 0.55, 1.0, 0.80};      // measured relative MFMA efficiency of the tile shapes
+        double eff[5] = {1.0, 0.78, 0.55, 1.0, 0.70};      // measured relative MFMA efficiency of the tile shapes
         if (p.KT <= 10) eff[1] = 1.1;                      // K <= 640: 3 resident 128x64 workgroups hide the short K loop's ends
         if (dtype != PSG_BF16) eff[3] = eff[4] = 0.0;      // 160 = 2 x 5 x 16: only the 16x16x32 bf16 tiles divide it
         const double slots = 512.0;                        // resident workgroups on the chip (2 per CU)
