@@ -244,6 +244,30 @@ def test_train_step_updates_and_decreases_loss(psg):
     assert ops.ParamShadow.lookup(w0) is None
 
 
+def test_train_step_is_run_to_run_deterministic(psg):
+    """Same weights, same batch, same seeds -> bit-identical loss, gradient norm and parameters after two steps, run
+    twice: every reduction is fixed-order (split-K slabs, column sums, GroupNorm, the gradient norm), no float atomics,
+    and the weight gradients computed on the second stream land in disjoint arena slices."""
+    def run():
+        torch.manual_seed(7)
+        psg.unet._SeedStream.counter = 0                      # dropout seeds = f(torch seed, running counter)
+        u = psg.UNet(compute_dtype=torch.bfloat16).to(DEV)
+        st = psg.DiffusionStepper(u, psg.NoiseScheduler(), lr=1e-4, distributed=False)
+        g = torch.Generator(device=DEV).manual_seed(11)
+        lat, txt = torch.randn(6, 8, 27, 27, device=DEV, generator=g), torch.randn(6, 32, 256, device=DEV, generator=g)
+        t = torch.tensor([3, 250, 500, 750, 990, 42], device=DEV)
+        nz = torch.randn(6, 8, 27, 27, device=DEV, generator=g)
+        outs = []
+        for _ in range(2):
+            r = st.train_step(lat, txt, t, nz)
+            outs.append((float(r["loss"].item()), float(r["grad_norm"].item())))
+        torch.cuda.synchronize()
+        return outs, st.params.flat.clone()
+    (o1, p1), (o2, p2) = run(), run()
+    assert o1 == o2, (o1, o2)
+    assert torch.equal(p1, p2)
+
+
 def test_sampler_trace_golden(psg, golden, full_unets):
     """20-step fast ddpm_sample with injected noise vs the reference's own ddpm_sample body (fixture)."""
     g = golden("sampler.npz")
