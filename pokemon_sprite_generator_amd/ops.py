@@ -70,9 +70,8 @@ class ParamShadow:
         cls._map[id(param)] = (arena, index, param)
 
     @classmethod
-    def unregister_arena(cls, arena):
-        for k in [k for k, v in cls._map.items() if v[0] is arena]:
-            del cls._map[k]
+    def clear(cls):
+        cls._map.clear()
 
     @classmethod
     def lookup(cls, param):

@@ -60,7 +60,8 @@ class ParamArena:
         copy_) is detected through its torch version counter and prepared from the fp32 master until the next step."""
         if self.shadow is None:
             self.shadow = self.flat.to(torch.bfloat16)
-            for i, p in enumerate(self.params):
+            ParamShadow.clear()              # one training arena at a time: an older arena (and its 10+ GB of buffers)
+            for i, p in enumerate(self.params):     # is released; its parameters fall back to the fp32 preparation path
                 ParamShadow.register(p, self, i)
         else:
             self.shadow.copy_(self.flat)
