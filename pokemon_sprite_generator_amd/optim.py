@@ -49,7 +49,7 @@ class ParamArena:
                     v = self.flat[o:o + p.numel()].view(p.shape)
                 v.copy_(p.data)
                 p.data = v
-        WeightCache.invalidate()
+        WeightCache.clear()              # (also releases prepared weights of models that are no longer trained)
         self.shadow = None               # bf16 copy of `flat`, kept current by FusedAdamW (enable_shadow)
         self._shadow_epoch = -1
         self._versions = None
