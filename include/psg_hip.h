@@ -48,6 +48,20 @@ enum psg_status {
 };
 enum psg_dtype { PSG_F32 = 0, PSG_BF16 = 1 };
 enum psg_act { PSG_ACT_NONE = 0, PSG_ACT_SILU = 1, PSG_ACT_GELU = 2 };
+/* Bits of the device-side NaN/Inf flag word of one train step (the reference's five host-side
+ * check_for_nans scans, improved_diffusion_trainer.py:353-393).  A step whose word has any bit of
+ * PSG_FLAG_SKIP_MASK set is skipped like the reference's `continue`: no optimizer step, no scheduler
+ * step.  PSG_FLAG_FALLBACK alone does NOT skip: add_noise replaced a non-finite result by
+ * x0 + 0.1*noise (:61-63) and the batch trains on that. */
+enum psg_flag {
+    PSG_FLAG_NOISY_BAD = 1,   /* noisy latent still non-finite after the fallback (:376) */
+    PSG_FLAG_T_RANGE = 2,     /* a timestep outside [0, num_t) (the reference raises an IndexError -> batch skipped) */
+    PSG_FLAG_PRED_BAD = 4,    /* predicted noise non-finite (:383) */
+    PSG_FLAG_LOSS_BAD = 8,    /* loss non-finite (:390) */
+    PSG_FLAG_FALLBACK = 16,   /* add_noise took the fallback (informational) */
+    PSG_FLAG_INPUT_BAD = 32,  /* text embedding / clean latent non-finite (:353,359; set by the host-side caller) */
+    PSG_FLAG_SKIP_MASK = 47
+};
 
 const char* psg_last_error(void);
 int psg_version(void);
@@ -61,14 +75,15 @@ int psg_init(int device);
 /* NoiseScheduler.add_noise — improved_diffusion_trainer.py:50-65 (+ clamp :363).
  * out[b,i] = tabA[t[b]] * clamp?(x0[b,i]) + tabB[t[b]] * noise[b,i]; two rounded
  * multiplies and one rounded add, bit-identical to the CPU path.  *flag (int32,
- * device) is OR-ed with 1 if any output is NaN/Inf, with 2 if any t[b] is
- * outside [0,num_t).  Zero *flag before the call. */
+ * device) is OR-ed with PSG_FLAG_FALLBACK if any output is NaN/Inf, with
+ * PSG_FLAG_T_RANGE if any t[b] is outside [0,num_t).  Zero *flag before the call. */
 int psg_noise_add_f32(const float* x0, const float* noise, const int64_t* t, const float* tabA,
                       const float* tabB, float* out, int32_t* flag, int64_t B, int64_t chw,
                       int num_t, int do_clamp, psg_stream_t stream);
-/* The reference's fallback (:61-63): if (*flag & 1) out = clamp?(x0) + 0.1*noise.  Device-side
+/* The reference's fallback (:61-63): if (*flag & PSG_FLAG_FALLBACK) out = clamp?(x0) + 0.1*noise, and
+ * *flag |= PSG_FLAG_NOISY_BAD if that is still non-finite (the trainer's re-check, :376).  Device-side
  * test of the flag; no host sync. */
-int psg_noise_fallback_f32(const float* x0, const float* noise, float* out, const int32_t* flag,
+int psg_noise_fallback_f32(const float* x0, const float* noise, float* out, int32_t* flag,
                            int64_t n, int do_clamp, psg_stream_t stream);
 /* ddpm_sample update — improved_diffusion_trainer.py:543-567.  step tables hold the per-timestep
  * scalars c1=1/sqrt(alpha_t), c2=beta_t/sqrt(1-alphabar_t), sigma=sqrt(beta_t) (fp32, computed on
@@ -125,6 +140,14 @@ int psg_groupnorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, 
                       const float* beta, const float* mean, const float* rstd, void* dx, int64_t lddx,
                       float* dgamma, float* dbeta, int B, int HW, int C, int G, int silu, int accumulate,
                       int dtype, void* ws, psg_stream_t stream);
+/* Same, with the gradient of the normalised tensor's OTHER consumer added in the same pass:
+ * dx = groupnorm_bwd(dy) + dres.  Every GroupNorm input of the U-Net also feeds a path that bypasses the norm
+ * (ResBlock skip, unet.py:132; the attention residuals :220,238), so autograd's separate accumulation pass over
+ * the activation gradient disappears.  dres may be NULL (then identical to psg_groupnorm_bwd) and may alias dx. */
+int psg_groupnorm_bwd_res(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* gamma,
+                          const float* beta, const float* mean, const float* rstd, const void* dres,
+                          int64_t lddres, void* dx, int64_t lddx, float* dgamma, float* dbeta, int B, int HW,
+                          int C, int G, int silu, int accumulate, int dtype, void* ws, psg_stream_t stream);
 int64_t psg_groupnorm_bwd_workspace_bytes(int B, int C);
 
 /* ---------------------------------------------------------------------------
@@ -244,12 +267,22 @@ int psg_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const v
 int psg_sumsq_f32(const float* g, int64_t n, float* out, int accumulate, void* ws, psg_stream_t stream);
 /* clip_grad_norm_ (:410) fused with AdamW (:277-283,412): coef = min(1, max_norm/(sqrt(*normsq)+1e-6))
  * read on the device (normsq may be NULL = no clipping); decoupled weight decay; step is 1-based.
- * skip_flag (may be NULL): when *skip_flag != 0 the update is skipped (NaN batch, :383-393).
+ * skip_flag (may be NULL): when (*skip_flag & PSG_FLAG_SKIP_MASK) != 0 the update is skipped (NaN batch, :353-393).
  * shadow_bf16 (may be NULL): bf16 copy of the updated parameters written in the same pass, element i at
  * shadow_bf16[i] — with OHWI master weights this IS the prepared forward weight of the next step. */
 int psg_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                   float beta2, float eps, float weight_decay, int step, const float* normsq,
                   float max_norm, const int32_t* skip_flag, void* shadow_bf16, psg_stream_t stream);
+/* The same update with the step count and the learning-rate schedule ON THE DEVICE, so that a skipped batch
+ * advances neither (the reference `continue`s before optimizer.step() / scheduler.step() / global_step += 1,
+ * :353-393,412-418) without a host read of the flag: step = *step_dev + 1 (1-based, bias correction computed in
+ * the kernel), lr = lr_table[k], beta1 = beta1_table[k] with k = min(step - 1, sched_len - 1) (entry k = the values
+ * the reference's scheduler holds after k scheduler.step() calls; OneCycleLR (:313-319) cycles Adam's beta1 along
+ * with the lr; beta1_table may be NULL = constant beta1), and *step_dev += 1 after the update unless skipped. */
+int psg_adamw_dev_f32(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_table,
+                      const float* beta1_table, int sched_len, float beta1, float beta2, float eps,
+                      float weight_decay, int32_t* step_dev, const float* normsq, float max_norm,
+                      const int32_t* skip_flag, void* shadow_bf16, psg_stream_t stream);
 /* g *= min(1, max_norm/(sqrt(*normsq)+1e-6)) — plain clip for callers that keep torch.optim. */
 int psg_clip_scale_f32(float* g, int64_t n, const float* normsq, float max_norm, psg_stream_t stream);
 

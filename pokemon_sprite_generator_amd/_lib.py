@@ -13,6 +13,8 @@ LIB_PATH = os.environ.get("PSG_LIB_PATH") or os.path.join(_HERE, "libpsg_hip.so"
 
 PSG_F32, PSG_BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
+# enum psg_flag: bits of the per-step NaN/Inf flag word
+FLAG_NOISY_BAD, FLAG_T_RANGE, FLAG_PRED_BAD, FLAG_LOSS_BAD, FLAG_FALLBACK, FLAG_INPUT_BAD, FLAG_SKIP_MASK = 1, 2, 4, 8, 16, 32, 47
 
 c_void_p, c_int, c_int64, c_float, c_uint64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_uint64
 
@@ -65,6 +67,8 @@ SIGNATURES = {
     "psg_groupnorm_fwd_workspace_bytes": (c_int64, [c_int, c_int]),
     "psg_groupnorm_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64] + [c_void_p] * 4 + [c_void_p, c_int64, c_void_p, c_void_p]
                           + [c_int] * 7 + [c_void_p, c_void_p]),
+    "psg_groupnorm_bwd_res": (c_int, [c_void_p, c_int64, c_void_p, c_int64] + [c_void_p] * 4 + [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p]
+                              + [c_int] * 7 + [c_void_p, c_void_p]),
     "psg_groupnorm_bwd_workspace_bytes": (c_int64, [c_int, c_int]),
     "psg_conv_fwd": (c_int, [C.POINTER(ConvDesc), c_void_p]),
     "psg_conv_wgrad": (c_int, [C.POINTER(WgradDesc), c_void_p]),
@@ -82,6 +86,7 @@ SIGNATURES = {
                      + [c_int] * 5 + [c_float, c_float, c_uint64, c_int, c_void_p]),
     "psg_sumsq_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p]),
     "psg_adamw_f32": (c_int, [c_void_p] * 4 + [c_int64] + [c_float] * 5 + [c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
+    "psg_adamw_dev_f32": (c_int, [c_void_p] * 4 + [c_int64, c_void_p, c_void_p, c_int] + [c_float] * 4 + [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "psg_clip_scale_f32": (c_int, [c_void_p, c_int64, c_void_p, c_float, c_void_p]),
     "psg_profile_begin": (c_int, []),
     "psg_profile_end": (c_int, [c_void_p, c_void_p, c_void_p, c_int]),

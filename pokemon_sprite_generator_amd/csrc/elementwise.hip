@@ -44,19 +44,24 @@ __global__ void noise_add_kernel(const float* __restrict__ x0, const float* __re
         if (do_clamp) x = fminf(fmaxf(x, -3.0f), 3.0f);
         const float r = __fadd_rn(__fmul_rn(a, x), __fmul_rn(c, noise[i]));
         out[i] = r;
-        if (isnan(r) || isinf(r)) bad |= 1;
+        if (isnan(r) || isinf(r)) bad |= PSG_FLAG_FALLBACK;      // the reference then returns x0 + 0.1*noise (:61-63)
     }
     if (bad) atomicOr(flag, bad);
 }
 
 __global__ void noise_fallback_kernel(const float* __restrict__ x0, const float* __restrict__ noise,
-                                      float* __restrict__ out, const int32_t* flag, int64_t n, int do_clamp) {
-    if (((*flag) & 1) == 0) return;
+                                      float* __restrict__ out, int32_t* flag, int64_t n, int do_clamp) {
+    // (workgroups that find the fallback bit set may OR bit 0 into the word below; the fallback bit itself is never cleared)
+    if (((*flag) & PSG_FLAG_FALLBACK) == 0) return;
+    int bad = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float x = x0[i];
         if (do_clamp) x = fminf(fmaxf(x, -3.0f), 3.0f);
-        out[i] = __fadd_rn(x, __fmul_rn(0.1f, noise[i]));
+        const float r = __fadd_rn(x, __fmul_rn(0.1f, noise[i]));
+        out[i] = r;
+        if (isnan(r) || isinf(r)) bad = PSG_FLAG_NOISY_BAD;     // the rescued batch is still non-finite: :376 skips it
     }
+    if (bad) atomicOr(flag, bad);
 }
 
 __global__ void ddpm_update_kernel(float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ z,
@@ -96,7 +101,7 @@ __global__ void smooth_l1_kernel(const float* __restrict__ pred, const float* __
     }
     const float s = block_sum(acc, red);
     if (threadIdx.x == 0) partial[blockIdx.x] = s;
-    if (bad && nan_flag) atomicOr(nan_flag, 4);
+    if (bad && nan_flag) atomicOr(nan_flag, PSG_FLAG_PRED_BAD);
 }
 
 __global__ void sumsq_kernel(const float* __restrict__ g, float* __restrict__ partial, int64_t n) {
@@ -124,7 +129,7 @@ __global__ void finish_sum_kernel(const float* __restrict__ partial, int count, 
         float r = s * scale;
         if (accumulate) r += *out;
         *out = r;
-        if (nan_flag && (isnan(r) || isinf(r))) atomicOr(nan_flag, 8);
+        if (nan_flag && (isnan(r) || isinf(r))) atomicOr(nan_flag, PSG_FLAG_LOSS_BAD);
     }
 }
 
@@ -316,11 +321,30 @@ __device__ __forceinline__ float clip_coef_dev(const float* normsq, float max_no
     return c < 1.0f ? c : 1.0f;
 }
 
+// Step count and learning rate either come from the host (step_dev == NULL: lr, bc1, bc2_sqrt as passed) or live on
+// the device: step = *step_dev + 1 counts the updates that really happened (a skipped NaN batch advances nothing,
+// improved_diffusion_trainer.py:353-393 `continue`), lr = lr_table[min(step - 1, lr_len - 1)] is the schedule value
+// the reference's scheduler.step() would have set after that many optimizer steps.
+struct AdamSched { const int32_t* step_dev; const float* lr_table; const float* beta1_table; int len; };
+__device__ __forceinline__ void adam_sched(const AdamSched& sc, float& beta1, float beta2, float& lr, float& bc1, float& bc2_sqrt) {
+    if (!sc.step_dev) return;
+    const int step = *sc.step_dev + 1;
+    const int k = min(step - 1, sc.len - 1);
+    if (sc.lr_table) lr = sc.lr_table[k];
+    if (sc.beta1_table) beta1 = sc.beta1_table[k];         // (torch computes the bias correction with the CURRENT beta1 too)
+    bc1 = 1.0f - powf(beta1, (float)step);
+    bc2_sqrt = sqrtf(1.0f - powf(beta2, (float)step));
+}
+__global__ void adam_step_advance_kernel(int32_t* step_dev, const int32_t* skip_flag) {
+    if (!(skip_flag && (*skip_flag & PSG_FLAG_SKIP_MASK))) *step_dev += 1;
+}
+
 __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                              float* __restrict__ v, int64_t n, float lr, float beta1, float beta2, float eps,
                              float wd, float bc1, float bc2_sqrt, const float* normsq, float max_norm,
-                             const int32_t* skip_flag) {
-    if (skip_flag && *skip_flag) return;
+                             const int32_t* skip_flag, const AdamSched sc) {
+    if (skip_flag && (*skip_flag & PSG_FLAG_SKIP_MASK)) return;
+    adam_sched(sc, beta1, beta2, lr, bc1, bc2_sqrt);
     const float coef = clip_coef_dev(normsq, max_norm);
     const float step_size = lr / bc1;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -338,8 +362,9 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 __global__ void adamw_kernel4(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                               float* __restrict__ v, int64_t n4, float lr, float beta1, float beta2, float eps,
                               float wd, float bc1, float bc2_sqrt, const float* normsq, float max_norm,
-                              const int32_t* skip_flag, bf16_t* __restrict__ shadow) {
-    if (skip_flag && *skip_flag) return;
+                              const int32_t* skip_flag, bf16_t* __restrict__ shadow, const AdamSched sc) {
+    if (skip_flag && (*skip_flag & PSG_FLAG_SKIP_MASK)) return;
+    adam_sched(sc, beta1, beta2, lr, bc1, bc2_sqrt);
     const float coef = clip_coef_dev(normsq, max_norm);
     const float step_size = lr / bc1;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -568,7 +593,7 @@ int psg_noise_add_f32(const float* x0, const float* noise, const int64_t* t, con
     return PSG_OK;
 }
 
-int psg_noise_fallback_f32(const float* x0, const float* noise, float* out, const int32_t* flag, int64_t n,
+int psg_noise_fallback_f32(const float* x0, const float* noise, float* out, int32_t* flag, int64_t n,
                            int do_clamp, psg_stream_t stream) {
     PSG_REQUIRE(x0 && noise && out && flag, PSG_ERR_ARG, "noise_fallback: null pointer");
     if (n <= 0) return PSG_OK;
@@ -617,6 +642,22 @@ int psg_sumsq_f32(const float* g, int64_t n, float* out, int accumulate, void* w
     return PSG_OK;
 }
 
+static int adamw_launch(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                        float weight_decay, float bc1, float bc2_sqrt, const float* normsq, float max_norm,
+                        const int32_t* skip_flag, void* shadow_bf16, const AdamSched& sc, psg_stream_t stream) {
+    const bool vec = n % 4 == 0 && aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v) && (!shadow_bf16 || aligned8(shadow_bf16));
+    PSG_REQUIRE(!shadow_bf16 || vec, PSG_ERR_ALIGN, "adamw: the bf16 shadow needs n %% 4 == 0 and 16-byte aligned buffers");
+    if (vec) {
+        hipLaunchKernelGGL(adamw_kernel4, dim3(grid_for(n / 4, 256, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n / 4, lr,
+                           beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, normsq, max_norm, skip_flag, (bf16_t*)shadow_bf16, sc);
+    } else {
+        hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr,
+                           beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, normsq, max_norm, skip_flag, sc);
+    }
+    PSG_LAUNCH_CHECK("adamw");
+    return PSG_OK;
+}
+
 int psg_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                   float eps, float weight_decay, int step, const float* normsq, float max_norm,
                   const int32_t* skip_flag, void* shadow_bf16, psg_stream_t stream) {
@@ -624,17 +665,20 @@ int psg_adamw_f32(float* p, const float* g, float* m, float* v, int64_t n, float
     PSG_REQUIRE(n > 0 && step >= 1, PSG_ERR_SHAPE, "adamw: n=%ld step=%d", (long)n, step);
     const float bc1 = 1.0f - powf(beta1, (float)step);
     const float bc2 = 1.0f - powf(beta2, (float)step);
-    const bool vec = n % 4 == 0 && aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v) && (!shadow_bf16 || aligned8(shadow_bf16));
-    PSG_REQUIRE(!shadow_bf16 || vec, PSG_ERR_ALIGN, "adamw: the bf16 shadow needs n %% 4 == 0 and 16-byte aligned buffers");
-    if (vec) {
-        hipLaunchKernelGGL(adamw_kernel4, dim3(grid_for(n / 4, 256, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n / 4, lr,
-                           beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), normsq, max_norm, skip_flag, (bf16_t*)shadow_bf16);
-        PSG_LAUNCH_CHECK("adamw");
-        return PSG_OK;
-    }
-    hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr,
-                       beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), normsq, max_norm, skip_flag);
-    PSG_LAUNCH_CHECK("adamw");
+    const AdamSched sc = {nullptr, nullptr, nullptr, 0};
+    return adamw_launch(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, sqrtf(bc2), normsq, max_norm, skip_flag, shadow_bf16, sc, stream);
+}
+
+int psg_adamw_dev_f32(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_table, const float* beta1_table,
+                      int sched_len, float beta1, float beta2, float eps, float weight_decay, int32_t* step_dev, const float* normsq,
+                      float max_norm, const int32_t* skip_flag, void* shadow_bf16, psg_stream_t stream) {
+    PSG_REQUIRE(p && g && m && v && lr_table && step_dev, PSG_ERR_ARG, "adamw_dev: null pointer");
+    PSG_REQUIRE(n > 0 && sched_len >= 1, PSG_ERR_SHAPE, "adamw_dev: n=%ld sched_len=%d", (long)n, sched_len);
+    const AdamSched sc = {step_dev, lr_table, beta1_table, sched_len};
+    const int rc = adamw_launch(p, g, m, v, n, 0.f, beta1, beta2, eps, weight_decay, 1.f, 1.f, normsq, max_norm, skip_flag, shadow_bf16, sc, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(adam_step_advance_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev, skip_flag);
+    PSG_LAUNCH_CHECK("adam_step_advance");
     return PSG_OK;
 }
 

@@ -27,9 +27,9 @@ constexpr int GN_U = GN_U_VALUE;     // loads in flight per lane, forward passes
 constexpr int GN_UB = GN_UB_VALUE;   // backward passes (two operands each)
 
 struct GnP {
-    const void *x, *dy; void *y, *dx;
+    const void *x, *dy, *dres; void *y, *dx;
     const float *gamma, *beta; float *mean, *rstd, *ws, *dgamma, *dbeta;
-    int64_t ldx, ldy, lddy, lddx;
+    int64_t ldx, ldy, lddy, lddx, lddres;
     int B, HW, C, G, Cg, CC, PP, NS, pps;   // CC chunks per row, PP pixel lanes, NS splits, pps pixels per split
     float eps; int silu, accumulate;
 };
@@ -234,13 +234,17 @@ __global__ void gn_bwd_apply_kernel(const GnP p) {
     const T* xb = reinterpret_cast<const T*>(p.x) + (int64_t)b * p.HW * p.ldx + c * N;
     const T* gb = reinterpret_cast<const T*>(p.dy) + (int64_t)b * p.HW * p.lddy + c * N;
     T* ob = reinterpret_cast<T*>(p.dx) + (int64_t)b * p.HW * p.lddx + c * N;
+    // optional gradient of the tensor's OTHER consumer (the residual / skip path that bypasses the norm): added here
+    // instead of by a separate autograd accumulation pass
+    const T* rb = p.dres ? reinterpret_cast<const T*>(p.dres) + (int64_t)b * p.HW * p.lddres + c * N : nullptr;
     for (int px = p0 + pl; px < p1; px += GN_UB * p.PP) {
-        float v[GN_UB][N], d[GN_UB][N];
+        float v[GN_UB][N], d[GN_UB][N], r[GN_UB][N];
 #pragma unroll
         for (int u = 0; u < GN_UB; ++u) {
             const int pu = px + u * p.PP, ps = pu < p1 ? pu : px;
             Vec<T>::ld(xb + (int64_t)ps * p.ldx, v[u]);
             Vec<T>::ld(gb + (int64_t)ps * p.lddy, d[u]);
+            if (rb) Vec<T>::ld(rb + (int64_t)ps * p.lddres, r[u]);
         }
 #pragma unroll
         for (int u = 0; u < GN_UB; ++u) {
@@ -251,6 +255,7 @@ __global__ void gn_bwd_apply_kernel(const GnP p) {
                 float dz = d[u][e];
                 if (p.silu) dz *= silu_grad(h * ga[e] + be[e]);
                 v[u][e] = rs[e] * (dz * ga[e] - s1[e] - h * s2[e]);
+                if (rb) v[u][e] += r[u][e];
             }
             if (pu < p1) Vec<T>::st(ob + (int64_t)pu * p.lddx, v[u]);
         }
@@ -345,16 +350,26 @@ int psg_groupnorm_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, const fl
 int psg_groupnorm_bwd(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* gamma, const float* beta,
                       const float* mean, const float* rstd, void* dx, int64_t lddx, float* dgamma, float* dbeta, int B,
                       int HW, int C, int G, int silu, int accumulate, int dtype, void* ws, psg_stream_t stream) {
+    return psg_groupnorm_bwd_res(dy, lddy, x, ldx, gamma, beta, mean, rstd, nullptr, 0, dx, lddx, dgamma, dbeta, B, HW, C, G, silu,
+                                 accumulate, dtype, ws, stream);
+}
+
+int psg_groupnorm_bwd_res(const void* dy, int64_t lddy, const void* x, int64_t ldx, const float* gamma, const float* beta,
+                          const float* mean, const float* rstd, const void* dres, int64_t lddres, void* dx, int64_t lddx,
+                          float* dgamma, float* dbeta, int B, int HW, int C, int G, int silu, int accumulate, int dtype, void* ws,
+                          psg_stream_t stream) {
     PSG_REQUIRE(dy && x && gamma && beta && mean && rstd && dx && dgamma && dbeta && ws, PSG_ERR_ARG, "groupnorm_bwd: null pointer");
     PSG_REQUIRE(dtype == PSG_F32 || dtype == PSG_BF16, PSG_ERR_DTYPE, "groupnorm_bwd: dtype %d", dtype);
     GnP p = {};
     p.x = x; p.dy = dy; p.dx = dx; p.gamma = gamma; p.beta = beta; p.mean = const_cast<float*>(mean); p.rstd = const_cast<float*>(rstd);
     p.ws = (float*)ws; p.ldx = ldx; p.lddy = lddy; p.lddx = lddx; p.B = B; p.HW = HW; p.C = C; p.G = G; p.silu = silu;
+    p.dres = dres; p.lddres = lddres;
     int rc = gn_plan(p, dtype);
     if (rc) return rc;
     const int N = dtype == PSG_BF16 ? 8 : 4;
     PSG_REQUIRE(ldx >= C && lddy >= C && lddx >= C && ldx % N == 0 && lddy % N == 0 && lddx % N == 0 && aligned16(x) && aligned16(dy) &&
                 aligned16(dx), PSG_ERR_ALIGN, "groupnorm_bwd: rows must be 16-byte aligned (ld multiple of %d)", N);
+    PSG_REQUIRE(!dres || (lddres >= C && lddres % N == 0 && aligned16(dres)), PSG_ERR_ALIGN, "groupnorm_bwd: dres rows must be 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const int threads = p.CC * p.PP, grid = B * p.NS;
     const size_t lds1 = (size_t)p.PP * C * 2 * sizeof(float), lds2 = ((size_t)C + G) * 2 * sizeof(float);

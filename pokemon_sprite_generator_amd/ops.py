@@ -13,7 +13,7 @@ import torch
 from . import _lib
 from ._lib import ACT_GELU, ACT_NONE, ACT_SILU, ConvDesc, WgradDesc, check, dtype_code, ptr, stream_ptr
 
-__all__ = ["conv2d", "linear", "group_norm", "attention_self", "attention_cross", "cross_in_proj", "upsample_bilinear",
+__all__ = ["conv2d", "linear", "group_norm", "group_norm_split", "attention_self", "attention_cross", "cross_in_proj", "upsample_bilinear",
            "nchw_to_nhwc", "nhwc_to_nchw", "text_pool", "timestep_sinusoid", "WeightCache", "ACT_NONE", "ACT_SILU", "ACT_GELU"]
 
 
@@ -23,9 +23,27 @@ def _lib_for(t):
     return _lib.init(t.device.index if t.device.index is not None else torch.cuda.current_device())
 
 
+class RowCopies:
+    """Counter of the hidden `.contiguous()` copies `_rows` had to make (irregular strides / misaligned rows): each one is
+    a full extra pass over an activation through HBM.  The U-Net path is expected to make none (asserted by
+    tests/test_unet_gpu.py); PSG_WARN_COPIES=1 logs the shape and strides of every offender."""
+    count = 0
+    bytes = 0
+    warn = os.environ.get("PSG_WARN_COPIES", "0") != "0"
+
+    @classmethod
+    def note(cls, t):
+        cls.count += 1
+        cls.bytes += t.numel() * t.element_size()
+        if cls.warn:
+            import warnings
+            warnings.warn(f"psg ops: layout copy of a {tuple(t.shape)} tensor with strides {tuple(t.stride())} (ptr%16={t.data_ptr() % 16})")
+
+
 def _rows(t):
-    """Collapse [..., C] with uniform row stride to (rows, ld); copies if the layout is irregular."""
+    """Collapse [..., C] with uniform row stride to (rows, ld); copies (and counts it, RowCopies) if the layout is irregular."""
     if t.stride(-1) != 1:
+        RowCopies.note(t)
         t = t.contiguous()
     C_ = t.shape[-1]
     ld = t.stride(-2) if t.dim() >= 2 else C_
@@ -37,6 +55,7 @@ def _rows(t):
             break
         expect = expect * t.shape[i]
     if not ok or (t.data_ptr() % 16) != 0 or (ld % 8) != 0:
+        RowCopies.note(t)
         t = t.contiguous()
         ld = C_
     return t, ld
@@ -70,6 +89,12 @@ class ParamShadow:
         cls._map[id(param)] = (arena, index, param)
 
     @classmethod
+    def unregister(cls, arena):
+        """Drop the entries that belong to `arena` (only those: another arena's parameters keep their shadow)."""
+        for k in [k for k, e in cls._map.items() if e[0] is arena]:
+            del cls._map[k]
+
+    @classmethod
     def clear(cls):
         cls._map.clear()
 
@@ -101,6 +126,12 @@ class WeightCache:
     def clear(cls):
         cls._entries.clear()
         cls.epoch += 1
+
+    @classmethod
+    def drop(cls, params):
+        """Release the prepared copies of these parameters only (their storage is about to move)."""
+        for p in params:
+            cls._entries.pop(id(p), None)
 
     @classmethod
     def get(cls, w, dtype, need_wd):
@@ -144,22 +175,37 @@ class GradSink:
     _map = {}
 
     class Entry:
-        __slots__ = ("view", "written", "index", "on_ready", "param")
+        __slots__ = ("view", "written", "index", "on_ready", "param", "owner")
 
     @classmethod
-    def register(cls, param, view, index, on_ready=None):
+    def register(cls, param, view, index, on_ready=None, owner=None):
+        """Make `view` the gradient sink of `param`.  A parameter has ONE sink: registering it again from another
+        owner (a second GradArena over the same model) displaces the first owner, which is told so
+        (`owner.displaced(param)`) and refuses to step from then on instead of silently accumulating through
+        autograd's AccumulateGrad into views nothing zeroes."""
+        old = cls._map.get(id(param))
+        if old is not None and old.param is param and old.owner is not None and old.owner is not owner:
+            old.owner.displaced(param)
         e = cls.Entry()
-        e.view, e.written, e.index, e.on_ready, e.param = view, False, index, on_ready, param
+        e.view, e.written, e.index, e.on_ready, e.param, e.owner = view, False, index, on_ready, param, owner
         cls._map[id(param)] = e
+        return e
+
+    @classmethod
+    def unregister(cls, owner):
+        """Remove the sinks registered by `owner` (and only those)."""
+        for k in [k for k, e in cls._map.items() if e.owner is owner]:
+            del cls._map[k]
 
     @classmethod
     def unregister_all(cls):
         cls._map.clear()
 
     @classmethod
-    def begin_step(cls):
+    def begin_step(cls, owner=None):
         for e in cls._map.values():
-            e.written = False
+            if owner is None or e.owner is owner:
+                e.written = False
 
     @classmethod
     def get(cls, param):
@@ -173,8 +219,8 @@ class GradSink:
             e.on_ready(e.index)
 
     @classmethod
-    def unwritten(cls):
-        return [e for e in cls._map.values() if not e.written]
+    def unwritten(cls, owner=None):
+        return [e for e in cls._map.values() if not e.written and (owner is None or e.owner is owner)]
 
 
 def _conv_launch(lib, dtype, x, ldx, w, ldw, y, ldy, geom, Cin, Cout, transposed=False, bias=None, rowadd=None,
@@ -249,6 +295,12 @@ class SideStream:
     enabled = os.environ.get("PSG_WGRAD_STREAM", "1") != "0"
     _streams = {}
     used = False
+    # Operands of the launches still in flight on the side stream.  Holding the Python reference does two things:
+    # the buffer cannot be recycled, and - the part that matters - autograd's gradient accumulation never adds IN PLACE
+    # into a tensor that something else still references (InputBuffer only re-uses a buffer whose use_count is 1).
+    # Without it `d_res = dy` (returned by _ConvFn.backward while the side-stream wgrad still reads dy) could be
+    # overwritten on the main stream by `dy += other_branch_gradient` under the wgrad's feet.
+    _pending = []
 
     @classmethod
     def get(cls, device):
@@ -259,10 +311,16 @@ class SideStream:
         return s
 
     @classmethod
+    def hold(cls, *tensors):
+        cls._pending.extend(t for t in tensors if t is not None)
+        cls.used = True
+
+    @classmethod
     def join(cls, device):
         if cls.used:
             torch.cuda.current_stream(device).wait_stream(cls.get(device))
             cls.used = False
+        cls._pending.clear()
 
 
 def _param_out(param):
@@ -377,7 +435,7 @@ class _ConvFn(torch.autograd.Function):
                 with torch.cuda.stream(side):
                     _wgrad_launch(lib, dtype, xr, ldx, g, ldg, wo, geom, Cin, Cout, accumulate=wacc, dbias=bo, accumulate_bias=bacc, scale=gate)
                 g.record_stream(side); xr.record_stream(side)
-                SideStream.used = True
+                SideStream.hold(g, xr, dy)
             else:
                 _wgrad_launch(lib, dtype, xr, ldx, g, ldg, wo, geom, Cin, Cout, accumulate=wacc, dbias=bo, accumulate_bias=bacc, scale=gate)
             dw = _param_ret(wo, we)
@@ -465,7 +523,7 @@ class _FFNFn(torch.autograd.Function):
                 with torch.cuda.stream(side):
                     _wgrad_launch(lib, dtype, xin, ldxin, g, ldg, wo, geo, cin, cout, accumulate=wacc, dbias=bo, accumulate_bias=bacc)
                 g.record_stream(side); xin.record_stream(side)
-                SideStream.used = True
+                SideStream.hold(g, xin)
             else:
                 _wgrad_launch(lib, dtype, xin, ldxin, g, ldg, wo, geo, cin, cout, accumulate=wacc, dbias=bo, accumulate_bias=bacc)
             return _param_ret(wo, we), _param_ret(bo, be)
@@ -556,8 +614,13 @@ def cross_in_proj(xn, tp, weight, bias):
 # GroupNorm (+SiLU)
 # ---------------------------------------------------------------------------
 class _GroupNormFn(torch.autograd.Function):
+    """y = GroupNorm(x) [+SiLU]; with `passthrough` the node has a second output that IS x (for the consumer that
+    bypasses the norm - ResBlock skip, attention residual): backward then receives both gradients and adds the
+    bypass one inside the GroupNorm-backward kernel (psg_groupnorm_bwd_res) instead of autograd running a separate
+    accumulation pass over the activation gradient."""
+
     @staticmethod
-    def forward(ctx, x, gamma, beta, groups, eps, silu):
+    def forward(ctx, x, gamma, beta, groups, eps, silu, passthrough=False):
         lib = _lib_for(x)
         dtype = x.dtype
         xr, ldx = _rows(x)
@@ -571,15 +634,22 @@ class _GroupNormFn(torch.autograd.Function):
         ctx.save_for_backward(xr, gamma, beta, stats)
         ctx.gamma_param, ctx.beta_param = gamma, beta
         ctx.meta = (B, HW, Cc, groups, silu, ldx, tuple(x.shape))
+        if passthrough:
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dpass=None):
         xr, gamma, beta, stats = ctx.saved_tensors
         B, HW, Cc, groups, silu, ldx, shape = ctx.meta
+        if dy is None:                               # only the bypass consumer produced a gradient
+            return dpass, None, None, None, None, None, None
         lib = _lib_for(dy)
         dtype = dy.dtype
         dyr, lddy = _rows(dy)
+        dres, lddres = (None, 0)
+        if dpass is not None:
+            dres, lddres = _rows(dpass if dpass.dtype == dtype else dpass.to(dtype))
         dx = torch.empty(shape, dtype=dtype, device=dy.device)
         eg, eb = GradSink.get(ctx.gamma_param), GradSink.get(ctx.beta_param)
         sink = eg is not None and eb is not None and eg.written == eb.written
@@ -590,19 +660,27 @@ class _GroupNormFn(torch.autograd.Function):
             db = torch.empty(Cc, dtype=torch.float32, device=dy.device)
             acc = False
         ws = _lib.workspace(lib.psg_groupnorm_bwd_workspace_bytes(B, Cc), dy.device)
-        check(lib.psg_groupnorm_bwd(ptr(dyr), lddy, ptr(xr), ldx, ptr(gamma), ptr(beta), ptr(stats[0]), ptr(stats[1]), ptr(dx), Cc,
-                                    ptr(dg), ptr(db), B, HW, Cc, groups, int(silu), int(acc), dtype_code(dtype), ptr(ws), stream_ptr()),
-              "psg_groupnorm_bwd")
+        check(lib.psg_groupnorm_bwd_res(ptr(dyr), lddy, ptr(xr), ldx, ptr(gamma), ptr(beta), ptr(stats[0]), ptr(stats[1]), ptr(dres), lddres,
+                                        ptr(dx), Cc, ptr(dg), ptr(db), B, HW, Cc, groups, int(silu), int(acc), dtype_code(dtype), ptr(ws),
+                                        stream_ptr()), "psg_groupnorm_bwd_res")
         if sink:
             GradSink.done(eg)
             GradSink.done(eb)
-            return dx, None, None, None, None, None
-        return dx, dg, db, None, None, None
+            return dx, None, None, None, None, None, None
+        return dx, dg, db, None, None, None, None
 
 
 def group_norm(x, gamma, beta, groups, eps=1e-5, silu=False):
     """nn.GroupNorm (+F.silu) on channels-last [B, ..., C]: unet.py:115,127,214,231,397."""
     return _GroupNormFn.apply(x, gamma, beta, groups, eps, silu)
+
+
+def group_norm_split(x, gamma, beta, groups, eps=1e-5, silu=False):
+    """(GroupNorm(x), x): use the second result wherever x itself is consumed next to the norm (skip / residual
+    paths), so the two gradients meet inside the GroupNorm-backward kernel (see _GroupNormFn)."""
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return _GroupNormFn.apply(x, gamma, beta, groups, eps, silu), x
+    return _GroupNormFn.apply(x, gamma, beta, groups, eps, silu, True)
 
 
 # ---------------------------------------------------------------------------

@@ -12,6 +12,14 @@ Out-of-scope collaborators (BERT text encoder, frozen VAE, data loaders,
 TensorBoard) are NOT re-implemented: they are taken from the reference package
 (`src.models`, `src.data`) when it is importable, or injected through
 `components=` (tests, benchmarks with synthetic latents).
+
+Bad-batch semantics are the reference's (:353-393): a batch whose text embedding,
+latent, noisy latent, prediction or loss is non-finite is skipped — no optimizer
+step, no scheduler step, no `global_step` increment, not part of the epoch mean —
+and a noisy latent rescued by add_noise's `x0 + 0.1*noise` fallback (:61-63) trains.
+The decision is made ON THE DEVICE (flag word, `psg_flag` in include/psg_hip.h):
+the step counter and the lr / beta1 schedule live in device memory and advance only
+on steps that happened, so the loop never reads the flag on the host.
 """
 import logging
 import os
@@ -21,8 +29,8 @@ from typing import Any, Dict, Optional
 import torch
 
 from . import _lib
-from ._lib import check, ptr, stream_ptr
-from .ddp import BucketedAllReduce
+from ._lib import FLAG_INPUT_BAD, FLAG_LOSS_BAD, FLAG_PRED_BAD, FLAG_SKIP_MASK, check, ptr, stream_ptr
+from .ddp import BucketedAllReduce, ShardedLoader, dist_info
 from .optim import FusedAdamW, GradArena, ParamArena
 from .scheduler import NoiseScheduler
 from .unet import UNet
@@ -49,7 +57,8 @@ class DiffusionStepper:
     """
 
     def __init__(self, unet: UNet, noise_scheduler: NoiseScheduler, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01,
-                 eps=1e-6, max_grad_norm=1.0, optimizer_type="adamw", distributed=None, bucket_bytes=64 << 20):
+                 eps=1e-6, max_grad_norm=1.0, optimizer_type="adamw", distributed=None, bucket_bytes=64 << 20,
+                 grad_bucket_dtype=torch.float32):
         self.unet, self.noise_scheduler = unet, noise_scheduler
         self.max_grad_norm = max_grad_norm
         self.device = next(unet.parameters()).device
@@ -57,7 +66,11 @@ class DiffusionStepper:
             raise _lib.PsgError("DiffusionStepper needs the U-Net on a GPU (HIP path only)")
         self.lib = _lib.init(self.device.index if self.device.index is not None else torch.cuda.current_device())
         self.reducer = None
+        if distributed is None:
+            distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
         self.params = ParamArena(unet.parameters())        # flat fp32 masters, conv weights OHWI
+        if distributed:
+            self.params.broadcast(src=0)                    # replicas equal by construction, not by RNG seeding
         if getattr(unet, "compute_dtype", None) == torch.bfloat16 and optimizer_type == "adamw" and not os.environ.get("PSG_NO_SHADOW"):
             self.params.enable_shadow()                     # AdamW also emits next step's bf16 forward weights
         self.arena = GradArena(unet.parameters(), on_ready=lambda i: self.reducer.on_ready(i) if self.reducer is not None else None)
@@ -67,12 +80,17 @@ class DiffusionStepper:
                                         param_arena=self.params, grad_arena=self.arena)
         else:
             self.optimizer = torch.optim.Adam(self.arena.params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
-        if distributed is None:
-            distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
-        self.reducer = BucketedAllReduce(self.arena.flat, self.arena.params, self.arena.offsets, bucket_bytes) if distributed else None
-        self.flag = torch.zeros(1, dtype=torch.int32, device=self.device)      # bit0 noisy, bit2 eps_hat, bit3 loss non-finite
+        self.reducer = BucketedAllReduce(self.arena.flat, self.arena.params, self.arena.offsets, bucket_bytes,
+                                         bucket_dtype=grad_bucket_dtype) if distributed else None
+        self.flag = torch.zeros(1, dtype=torch.int32, device=self.device)      # bits: enum psg_flag (include/psg_hip.h)
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.criterion_beta = 0.1                                               # nn.SmoothL1Loss(beta=0.1) :300
+        self.host_steps = 0                                                     # (torch.optim.Adam branch only)
+
+    def close(self):
+        """Release the process-wide registrations (gradient sinks, bf16 shadow) of this stepper."""
+        self.arena.release()
+        self.params.release()
 
     # ---- fused SmoothL1 + dL/d(eps_hat) ------------------------------------------------------------
     def smooth_l1(self, pred, target, want_grad=True):
@@ -83,15 +101,27 @@ class DiffusionStepper:
                                          pred_c.numel(), ptr(ws), stream_ptr()), "psg_smooth_l1_f32")
         return self.loss, grad
 
-    def train_step(self, latents, text_emb, t, noise=None, lr=None) -> Dict[str, torch.Tensor]:
+    def _reduce_flag(self):
+        """All ranks must skip together: if ANY rank has a skip bit, every rank ends up with a non-zero skip field
+        (RCCL has no bitwise-OR reduction: MAX of the masked field keeps 'non-zero'; the local informational bits stay)."""
+        skip = self.flag & FLAG_SKIP_MASK
+        torch.distributed.all_reduce(skip, op=torch.distributed.ReduceOp.MAX)
+        self.flag.copy_((self.flag & ~FLAG_SKIP_MASK) | skip)
+
+    def train_step(self, latents, text_emb, t, noise=None, lr=None, pre_flag=None) -> Dict[str, torch.Tensor]:
         """One optimizer step on a batch of clean latents (the body of train_epoch, :363-413).
 
         latents [B,8,27,27] fp32 (un-clamped VAE output), text_emb [B,S,text_dim], t [B] int64, optional
-        noise (default randn_like).  Returns device tensors {'loss','grad_norm','nan_flag'} (no sync)."""
+        noise (default randn_like).  `pre_flag` (int32 device tensor or None) is OR-ed into the step's flag word
+        (the caller's own input checks, :353,359).  Returns device tensors {'loss','grad_norm','nan_flag'} (no sync);
+        a step whose flag has a bit of FLAG_SKIP_MASK leaves parameters, optimizer state, step count and schedule
+        untouched."""
         self.unet.train()
         if noise is None:
             noise = torch.randn_like(latents)
         self.flag.zero_()
+        if pre_flag is not None:
+            self.flag |= pre_flag.to(device=self.device, dtype=torch.int32).reshape(-1)[:1]
         noisy = self.noise_scheduler.add_noise(latents, noise, t, clamp=True, flag=self.flag)     # :363, :374
         self.arena.zero()                                                                           # :380
         eps_hat = self.unet(noisy, t, text_emb)                                                     # :381
@@ -100,20 +130,25 @@ class DiffusionStepper:
         self.arena.finalize()                      # (joins the weight-gradient side stream)
         if self.reducer is not None:
             self.reducer.finish()
-            torch.distributed.all_reduce(self.flag, op=torch.distributed.ReduceOp.MAX)              # all ranks skip together
+            self._reduce_flag()
         normsq = self.arena.grad_norm_sq()                                                          # :399-404
         if lr is not None:
             for g in self.optimizer.param_groups:
                 g["lr"] = lr
         if isinstance(self.optimizer, FusedAdamW):
             self.optimizer.step(normsq=normsq, max_norm=self.max_grad_norm, skip_flag=self.flag)    # :410-412
-        else:
+        elif (int(self.flag.item()) & FLAG_SKIP_MASK) == 0:      # torch.optim.Adam: the host decides (one sync per step)
             check(self.lib.psg_clip_scale_f32(ptr(self.arena.flat), self.arena.numel, ptr(normsq), float(self.max_grad_norm),
                                               stream_ptr()), "psg_clip_scale_f32")
             self.optimizer.step()
+            self.host_steps += 1
             from .ops import WeightCache
             WeightCache.invalidate()
         return {"loss": loss.clone(), "grad_norm": normsq.sqrt(), "nan_flag": self.flag.clone()}
+
+    def steps_done(self) -> int:
+        """Optimizer steps that really happened (host sync for the fused optimizer)."""
+        return self.optimizer.steps_done() if isinstance(self.optimizer, FusedAdamW) else self.host_steps
 
     @torch.no_grad()
     def eval_loss(self, latents, text_emb, t, noise=None):
@@ -127,70 +162,6 @@ class DiffusionStepper:
         loss, _ = self.smooth_l1(eps_hat, noise, want_grad=False)
         return loss.clone(), self.flag.clone()
 
-    @torch.no_grad()
-    def sample(self, text_emb, num_samples, fast_sampling=True, noise_fn=None, latent_dim=8, hw=27, trace=None, use_graph=None):
-        """ddpm_sample (:508-569): x <- (x - c2*eps)/sqrt(alpha_t) [+ sqrt(beta_t)*z if t>0], t strided by 50 when fast.
-        noise_fn(i, shape) -> tensor supplies x_T (i = -1) and the per-step z (tests inject it); default torch.randn.
-
-        use_graph=True (or PSG_GRAPH=1) captures the loop body (U-Net forward + update, ~700 launches) ONCE into a
-        hipGraph (torch.cuda.CUDAGraph over the library's launches on the capture stream) and replays it per step:
-        the timestep lives in device memory (the embedding and the update kernel both read it there) and z is
-        refilled in place, so the captured work is identical for every step; results are bit-identical to the eager
-        path (tests/test_unet_gpu.py).  It is opt-in because it does not pay on MI355X at sampling batch sizes
-        (tools/sampler_bench.py: 8.2 vs 7.8 ms/step at B=1..16): the step is bound by the GPU-side latency of ~700
-        small dependent kernels, not by host launch cost.  A capture failure falls back to eager with a warning."""
-        self.unet.eval()
-        dev = self.device
-        rnd = noise_fn if noise_fn is not None else (lambda i, shape: torch.randn(shape, device=dev))
-        x = rnd(-1, (num_samples, latent_dim, hw, hw)).to(dev).float().contiguous()
-        sch = self.noise_scheduler.to(dev)
-        c1, c2, sg = sch.step_tables(dev)
-        T = sch.num_timesteps
-        steps = list(range(0, T, 50)) if fast_sampling else list(range(T))
-        t_dev = torch.zeros(1, dtype=torch.int32, device=dev)
-        tv = torch.zeros((num_samples,), device=dev, dtype=torch.long)
-        z = torch.zeros_like(x)
-        text_emb = text_emb.to(dev)
-        if use_graph is None:
-            use_graph = bool(os.environ.get("PSG_GRAPH"))
-
-        def body():
-            eps = self.unet(x, tv, text_emb).contiguous()
-            check(self.lib.psg_ddpm_update_f32(ptr(x), ptr(eps), ptr(z), ptr(c1), ptr(c2), ptr(sg), ptr(t_dev), x.numel(), stream_ptr()),
-                  "psg_ddpm_update_f32")
-
-        graph = None
-        order = list(reversed(steps))
-        first = 0
-        if use_graph and len(order) > 2:
-            try:
-                # step 0 runs eagerly: it sizes the workspace and fills the prepared-weight cache (no allocation and
-                # no weight preparation may happen inside the capture), and it is a real step of the chain
-                self._sample_set(order[0], 0, tv, t_dev, z, rnd, x)
-                body()
-                if trace is not None:
-                    trace.append(x.clone())
-                first = 1
-                torch.cuda.synchronize(dev)
-                graph = torch.cuda.CUDAGraph()
-                self._sample_set(order[1], 1, tv, t_dev, z, rnd, x)
-                x_before = x.clone()
-                with torch.cuda.graph(graph):
-                    body()
-                x.copy_(x_before)                       # capture does not execute: the replay below runs step 1
-            except Exception as e:                      # noqa: BLE001
-                logging.getLogger(__name__).warning(f"hipGraph capture of the sampler step failed ({e!r}); running eagerly")
-                graph = None
-        for i in range(first, len(order)):
-            self._sample_set(order[i], i, tv, t_dev, z, rnd, x)
-            if graph is not None:
-                graph.replay()
-            else:
-                body()
-            if trace is not None:
-                trace.append(x.clone())
-        return x
-
     @staticmethod
     def _sample_set(t, i, tv, t_dev, z, rnd, x):
         """Per-step inputs, written in place (the captured graph reads these buffers)."""
@@ -199,9 +170,118 @@ class DiffusionStepper:
         if t > 0:
             z.copy_(rnd(i, tuple(x.shape)).to(device=x.device, dtype=torch.float32))
 
+    @torch.no_grad()
+    def sample(self, text_emb, num_samples, fast_sampling=True, noise_fn=None, latent_dim=8, hw=27, trace=None, use_graph=None,
+               max_steps=None):
+        """ddpm_sample (:508-569): x <- (x - c2*eps)/sqrt(alpha_t) [+ sqrt(beta_t)*z if t>0], t strided by 50 when fast.
+        noise_fn(i, shape) -> tensor supplies x_T (i = -1) and the per-step z (tests inject it); default torch.randn.
+        `max_steps` runs only the first that many steps of the chain (benchmarks / property tests of the 1000-step loop).
+        See SamplerRun for the hipGraph form (use_graph=True or PSG_GRAPH=1; bit-identical to the eager loop)."""
+        run = SamplerRun(self, text_emb, num_samples, fast_sampling, noise_fn, latent_dim, hw, use_graph, max_steps)
+        while run.remaining():
+            run.step()
+            if trace is not None:
+                trace.append(run.x.clone())
+        return run.x
+
+    def sampler(self, text_emb, num_samples, fast_sampling=True, noise_fn=None, latent_dim=8, hw=27, use_graph=None, max_steps=None):
+        """The same chain, one `step()` at a time (bench.py times single denoising steps)."""
+        return SamplerRun(self, text_emb, num_samples, fast_sampling, noise_fn, latent_dim, hw, use_graph, max_steps)
+
+
+class SamplerRun:
+    """One ddpm_sample chain (:508-569), advanced step by step.
+
+    use_graph=True (or PSG_GRAPH=1) captures the loop body (U-Net forward + update, ~700 launches) ONCE into a hipGraph
+    (torch.cuda.CUDAGraph over the library's launches on the capture stream) and replays it per step: the timestep lives
+    in device memory (the embedding and the update kernel both read it there) and z is refilled in place, so the
+    captured work is identical for every step; results are bit-identical to the eager path (tests/test_unet_gpu.py).
+    Step 0 always runs eagerly - it sizes the workspace and fills the prepared-weight cache (no allocation and no weight
+    preparation may happen inside the capture) - and the capture happens at step 1.  A capture failure falls back to the
+    eager loop with a warning."""
+
+    @torch.no_grad()
+    def __init__(self, stepper, text_emb, num_samples, fast_sampling=True, noise_fn=None, latent_dim=8, hw=27, use_graph=None,
+                 max_steps=None):
+        self.st = stepper
+        stepper.unet.eval()
+        dev = stepper.device
+        self.rnd = noise_fn if noise_fn is not None else (lambda i, shape: torch.randn(shape, device=dev))
+        self.x = self.rnd(-1, (num_samples, latent_dim, hw, hw)).to(dev).float().contiguous()
+        sch = stepper.noise_scheduler.to(dev)
+        self.c1, self.c2, self.sg = sch.step_tables(dev)
+        T = sch.num_timesteps
+        steps = list(range(0, T, 50)) if fast_sampling else list(range(T))
+        self.order = list(reversed(steps))
+        if max_steps is not None:
+            self.order = self.order[:max_steps]
+        self.t_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.tv = torch.zeros((num_samples,), device=dev, dtype=torch.long)
+        self.z = torch.zeros_like(self.x)
+        self.text = text_emb.to(dev)
+        if use_graph is None:
+            use_graph = bool(os.environ.get("PSG_GRAPH"))
+        self.use_graph = bool(use_graph) and len(self.order) > 2
+        self.graph = None
+        self.i = 0
+
+    def remaining(self):
+        return len(self.order) - self.i
+
+    def _body(self):
+        st = self.st
+        eps = st.unet(self.x, self.tv, self.text).contiguous()
+        check(st.lib.psg_ddpm_update_f32(ptr(self.x), ptr(eps), ptr(self.z), ptr(self.c1), ptr(self.c2), ptr(self.sg), ptr(self.t_dev),
+                                         self.x.numel(), stream_ptr()), "psg_ddpm_update_f32")
+
+    @torch.no_grad()
+    def step(self):
+        if self.i >= len(self.order):
+            raise StopIteration("sampler chain is complete")
+        self.st.unet.eval()
+        DiffusionStepper._sample_set(self.order[self.i], self.i, self.tv, self.t_dev, self.z, self.rnd, self.x)
+        if self.use_graph and self.i == 1 and self.graph is None:
+            try:
+                torch.cuda.synchronize(self.st.device)
+                graph = torch.cuda.CUDAGraph()
+                x_before = self.x.clone()
+                with torch.cuda.graph(graph):
+                    self._body()
+                self.x.copy_(x_before)                  # capture does not execute: the replay below runs this step
+                self.graph = graph
+            except Exception as e:                      # noqa: BLE001
+                logging.getLogger(__name__).warning(f"hipGraph capture of the sampler step failed ({e!r}); running eagerly")
+                self.use_graph = False
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._body()
+        self.i += 1
+        return self.x
+
+
+def schedule_tables(make_scheduler, lr, betas, total):
+    """(lr[k], beta1[k]) for k = 0..total-1 completed steps, produced by running the reference's own scheduler class on a
+    one-parameter dummy optimizer (OneCycleLR also cycles Adam's beta1, torch/optim/lr_scheduler.py) - no re-derivation."""
+    dummy = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=lr, betas=betas)
+    sch = make_scheduler(dummy)
+    lrs, b1s = [], []
+    for k in range(max(1, total)):
+        g = dummy.param_groups[0]
+        lrs.append(float(g["lr"])); b1s.append(float(g["betas"][0]))
+        if k + 1 < total:
+            dummy.step()
+            sch.step()
+    return lrs, b1s
+
 
 class ImprovedDiffusionTrainer:
-    """Drop-in for the reference class of the same name (stage-2 diffusion trainer)."""
+    """Drop-in for the reference class of the same name (stage-2 diffusion trainer).
+
+    Data parallel: when a default process group exists (`torchrun ... train_3stage.py` with
+    `torch.distributed.init_process_group("nccl")` called before the trainer is built - see INTEGRATION.md) every
+    rank builds the same trainer; gradients are averaged by the stepper, each rank trains on its own slice of every
+    batch (`ddp.ShardedLoader`), and only rank 0 writes checkpoints, TensorBoard events, sample images and the log file."""
 
     def __init__(self, config: Dict[str, Any], vae_checkpoint_path: str, experiment_name: str = "pokemon_diffusion",
                  components: Optional[Dict[str, Any]] = None, compute_dtype: Optional[torch.dtype] = None):
@@ -212,9 +292,12 @@ class ImprovedDiffusionTrainer:
             compute_dtype = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32,
                              "float32": torch.float32}[str(mi.get("dtype", "bf16"))]
         self.compute_dtype = compute_dtype
+        self._grad_bucket_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[str(mi.get("grad_bucket_dtype", "fp32"))]
         if not torch.cuda.is_available():
             raise _lib.PsgError("ImprovedDiffusionTrainer (MI355X build) needs a GPU; there is no CPU fallback")
         self.device = torch.device("cuda", torch.cuda.current_device())
+        self.rank, self.world = dist_info()
+        self.is_main = self.rank == 0
         print(f"Using device: {self.device}")
         self.setup_directories()
         self.setup_logging()
@@ -223,7 +306,8 @@ class ImprovedDiffusionTrainer:
         self.setup_optimization()
         self.setup_scheduler()
         self.setup_monitoring()
-        self.current_epoch, self.global_step, self.best_val_loss = 0, 0, float("inf")
+        self.current_epoch, self.best_val_loss = 0, float("inf")
+        self._gs_offset = 0
 
     # -- setup (plain Python glue, same keys as the reference) -----------------------------------------
     def setup_directories(self):
@@ -233,9 +317,18 @@ class ImprovedDiffusionTrainer:
             d.mkdir(parents=True, exist_ok=True)
 
     def setup_logging(self):
-        logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(levelname)s - %(message)s",
-                            handlers=[logging.FileHandler(self.log_dir / "diffusion_training.log"), logging.StreamHandler()])
+        fmt = "%(asctime)s - %(levelname)s - %(message)s"
+        logging.basicConfig(level=logging.INFO if self.is_main else logging.WARNING, format=fmt, handlers=[logging.StreamHandler()])
         self.logger = logging.getLogger(__name__)
+        if self.is_main:                                 # one log file, written by rank 0 (basicConfig is a no-op when the
+            path = str((self.log_dir / "diffusion_training.log").resolve())   # host application configured logging first)
+            root = logging.getLogger()
+            if not any(isinstance(h, logging.FileHandler) and h.baseFilename == path for h in root.handlers):
+                fh = logging.FileHandler(path)
+                fh.setFormatter(logging.Formatter(fmt))
+                root.addHandler(fh)
+            if root.level > logging.INFO or root.level == logging.NOTSET:
+                root.setLevel(logging.INFO)
 
     def _component(self, name):
         if name in self._components:
@@ -282,47 +375,93 @@ class ImprovedDiffusionTrainer:
 
     def setup_data_loaders(self):
         if "data_loaders" in self._components:
-            self.data_loaders = self._components["data_loaders"]
-            return
-        dc, uc = self.config["data"], self.config.get("unet_optimization", {}) or {}
-        bs, nw = uc.get("batch_size", dc["batch_size"]), uc.get("num_workers", dc["num_workers"])
-        tr, va, te = self._component("create_data_loaders")(csv_path=dc["csv_path"], image_dir=dc["image_dir"], batch_size=bs,
-                                                            val_split=dc["val_split"], test_split=dc["test_split"], image_size=dc["image_size"],
-                                                            num_workers=nw, pin_memory=dc["pin_memory"])
-        self.data_loaders = {"train": tr, "val": va, "test": te}
-        self.logger.info(f"Data loaders created: train={len(tr)}, val={len(va)}, test={len(te)}")
+            loaders = dict(self._components["data_loaders"])
+        else:
+            dc, uc = self.config["data"], self.config.get("unet_optimization", {}) or {}
+            bs, nw = uc.get("batch_size", dc["batch_size"]), uc.get("num_workers", dc["num_workers"])
+            tr, va, te = self._component("create_data_loaders")(csv_path=dc["csv_path"], image_dir=dc["image_dir"], batch_size=bs,
+                                                                val_split=dc["val_split"], test_split=dc["test_split"],
+                                                                image_size=dc["image_size"], num_workers=nw, pin_memory=dc["pin_memory"])
+            loaders = {"train": tr, "val": va, "test": te}
+            self.logger.info(f"Data loaders created: train={len(tr)}, val={len(va)}, test={len(te)}")
+        if self.world > 1:
+            # the reference's loaders know nothing about ranks: every rank iterates the same global batches (same
+            # seeding - documented requirement) and keeps its own contiguous slice of each
+            loaders["train"] = ShardedLoader(loaders["train"], self.rank, self.world)
+        self.data_loaders = loaders
 
     def setup_optimization(self):
         uc, oc = self.config.get("unet_optimization", {}) or {}, self.config["optimization"]
         get = lambda k, default=None: uc.get(k, oc.get(k, default))      # safe fallbacks (the reference KeyErrors on beta1/beta2)
         lr, self.max_grad_norm = get("learning_rate"), get("max_grad_norm")
-        self.stepper = DiffusionStepper(self.unet, self.noise_scheduler, lr=lr, betas=(get("beta1", 0.9), get("beta2", 0.999)),
+        self._betas = (get("beta1", 0.9), get("beta2", 0.999))
+        self.stepper = DiffusionStepper(self.unet, self.noise_scheduler, lr=lr, betas=self._betas,
                                         weight_decay=get("weight_decay"), eps=1e-6, max_grad_norm=self.max_grad_norm,
-                                        optimizer_type=get("optimizer", "adamw"))
+                                        optimizer_type=get("optimizer", "adamw"), grad_bucket_dtype=self._grad_bucket_dtype)
         self.optimizer = self.stepper.optimizer
         self.scheduler_config = {"type": uc.get("scheduler", oc.get("scheduler", "cosine")), "lr": lr}
         self.logger.info(f"Using U-Net optimization: {get('optimizer', 'adamw')}, lr={lr}, wd={get('weight_decay')}, clip={self.max_grad_norm}")
 
-    def setup_scheduler(self):
+    def _make_scheduler(self, optimizer):
         if self.scheduler_config["type"] == "cosine":
-            total = self.config["training"]["diffusion_epochs"] * len(self.data_loaders["train"])
-            self.scheduler = torch.optim.lr_scheduler.OneCycleLR(self.optimizer, max_lr=self.scheduler_config["lr"], total_steps=total,
-                                                                 pct_start=0.1, anneal_strategy="cos")
-        else:
-            self.scheduler = torch.optim.lr_scheduler.ConstantLR(self.optimizer, factor=1.0)
+            return torch.optim.lr_scheduler.OneCycleLR(optimizer, max_lr=self.scheduler_config["lr"], total_steps=self._total_steps,
+                                                       pct_start=0.1, anneal_strategy="cos")
+        return torch.optim.lr_scheduler.ConstantLR(optimizer, factor=1.0)
+
+    def setup_scheduler(self):
+        self._total_steps = max(1, self.config["training"]["diffusion_epochs"] * len(self.data_loaders["train"]))
+        if self.scheduler_config["type"] == "cosine":
+            self.logger.info(f"OneCycleLR total_steps: {self._total_steps}")
+        # the host-side scheduler object keeps the reference's checkpoint format ('scheduler_state_dict'); the schedule
+        # the kernels follow is the same class's output, tabulated per completed-step count
+        self.scheduler = self._make_scheduler(self.optimizer)
+        self._fused = isinstance(self.optimizer, FusedAdamW)
+        if self._fused:
+            n = self._total_steps if self.scheduler_config["type"] == "cosine" else 1
+            lrs, b1s = schedule_tables(self._make_scheduler, self.scheduler_config["lr"], self._betas, n)
+            self._lr_host, self._b1_host = lrs, b1s
+            self.optimizer.set_lr_table(lrs, b1s)
 
     def setup_monitoring(self):
+        self.writer = _NullWriter()
+        if not self.is_main:
+            return
         try:
             from torch.utils.tensorboard import SummaryWriter
             self.writer = SummaryWriter(log_dir=self.log_dir)
         except Exception:                      # tensorboard is optional here
-            self.writer = _NullWriter()
+            pass
+
+    # -- step counters: the truth is on the device ---------------------------------------------------------
+    @property
+    def global_step(self) -> int:
+        """Optimizer steps that happened (:418).  Reads the device counter: one host sync."""
+        return self.stepper.steps_done() + self._gs_offset
+
+    @global_step.setter
+    def global_step(self, value: int):
+        self._gs_offset = int(value) - self.stepper.steps_done()
+
+    def _sync_host_schedule(self):
+        """Bring the host-side scheduler / param_groups (logging, checkpoints) to the device step count."""
+        if not self._fused:
+            return
+        k = self.optimizer.steps_done()
+        i = min(k, len(self._lr_host) - 1)
+        g = self.optimizer.param_groups[0]
+        g["lr"] = self._lr_host[i]
+        g["betas"] = (self._b1_host[i], g["betas"][1])
+        self.scheduler.last_epoch = k
+        self.scheduler._step_count = k + 1
+        self.scheduler._last_lr = [g["lr"]]
 
     # -- facade ---------------------------------------------------------------------------------------
-    def train_step(self, latents, text_emb, t, noise=None):
-        out = self.stepper.train_step(latents, text_emb, t, noise)
-        self.scheduler.step()
-        self.global_step += 1
+    def train_step(self, latents, text_emb, t, noise=None, pre_flag=None):
+        """The loop body :363-413 on clean latents; see DiffusionStepper.train_step.  No host sync with the fused
+        optimizer: the step count and the lr / beta1 schedule advance on the device, and only when the step happened."""
+        out = self.stepper.train_step(latents, text_emb, t, noise, pre_flag=pre_flag)
+        if not self._fused and (int(out["nan_flag"].item()) & FLAG_SKIP_MASK) == 0:
+            self.scheduler.step()                                                                    # :413
         return out
 
     def sample(self, text_emb, num_samples, fast_sampling=True, noise_fn=None):
@@ -333,61 +472,75 @@ class ImprovedDiffusionTrainer:
 
     # -- epochs ----------------------------------------------------------------------------------------
     def _encode(self, batch):
+        """text embedding + frozen-VAE latent (:347-360) and the device-side form of their two NaN checks."""
         images = batch["image"].to(self.device)
         with torch.no_grad():
             text_emb = self.text_encoder(batch["full_description"])
             latent = self.vae_encoder(images)
             latent = latent[0] if isinstance(latent, (tuple, list)) else latent
-        return latent.float(), text_emb.float()
+            latent, text_emb = latent.float(), text_emb.float()
+            bad = ~(torch.isfinite(text_emb).all() & torch.isfinite(latent).all())
+        return latent, text_emb, bad.to(torch.int32).reshape(1) * FLAG_INPUT_BAD
 
     def train_epoch(self, epoch: int) -> Dict[str, float]:
-        total, nb, nan_count = torch.zeros(1, device=self.device), 0, 0
+        dev = self.device
+        total = torch.zeros(1, device=dev)                              # sum of the losses of the batches that trained
+        counts = torch.zeros(2, dtype=torch.int64, device=dev)          # [batches that trained, NaN batches (:384,392)]
         log_every = self.config["training"]["log_every"]
         for batch_idx, batch in enumerate(self.data_loaders["train"]):
             try:
-                latent, text_emb = self._encode(batch)
-                t = torch.randint(0, self.noise_scheduler.num_timesteps, (latent.shape[0],), device=self.device)
-                out = self.train_step(latent, text_emb, t)
+                latent, text_emb, pre = self._encode(batch)
+                t = torch.randint(0, self.noise_scheduler.num_timesteps, (latent.shape[0],), device=dev)
+                out = self.train_step(latent, text_emb, t, pre_flag=pre)
+                flag = out["nan_flag"]
+                good = (flag & FLAG_SKIP_MASK) == 0
+                total += torch.where(good, out["loss"], torch.zeros_like(out["loss"]))
+                counts[0] += good.reshape(()).to(torch.int64)
+                counts[1] += ((flag & (FLAG_PRED_BAD | FLAG_LOSS_BAD)) != 0).reshape(()).to(torch.int64)
                 if batch_idx % log_every == 0:                      # the only host syncs of the loop
-                    if int(out["nan_flag"].item()) != 0:
-                        nan_count += 1
-                        self.logger.warning("NaN/Inf detected, batch skipped")
+                    if int(flag.item()) & FLAG_SKIP_MASK:
+                        self.logger.warning(f"NaN/Inf detected (flag {int(flag.item())}), batch skipped")
                         continue
-                    self.writer.add_scalar("Diffusion Train/Loss", out["loss"].item(), self.global_step)
-                    self.writer.add_scalar("Diffusion Train/Learning_Rate", self.optimizer.param_groups[0]["lr"], self.global_step)
-                    self.writer.add_scalar("Diffusion Train/Gradient_Norm", out["grad_norm"].item(), self.global_step)
-                total += torch.where(out["nan_flag"] == 0, out["loss"], torch.zeros_like(out["loss"]))
-                nb += 1
+                    self._sync_host_schedule()
+                    step = self.global_step
+                    self.writer.add_scalar("Diffusion Train/Loss", out["loss"].item(), step)
+                    self.writer.add_scalar("Diffusion Train/Learning_Rate", self.optimizer.param_groups[0]["lr"], step)
+                    self.writer.add_scalar("Diffusion Train/Gradient_Norm", out["grad_norm"].item(), step)
             except Exception as e:                                 # noqa: BLE001  (reference :433-435 logs and continues)
                 self.logger.error(f"Error in training batch {batch_idx}: {e}")
                 continue
+        nb, nan_count = (int(v) for v in counts.tolist())
         if nb == 0:
             self.logger.error("No valid batches processed!")
             return {"train_loss": float("inf")}
         avg = float(total.item()) / nb
+        self._sync_host_schedule()
         self.logger.info(f"Epoch {epoch}: Average loss = {avg:.6f}, NaN batches = {nan_count}, LR = {self.optimizer.param_groups[0]['lr']:.2e}")
         return {"train_loss": avg}
 
     def validate_epoch(self, epoch: int) -> Dict[str, float]:
-        total, nb = 0.0, 0
+        dev = self.device
+        total, nb = torch.zeros(1, device=dev), torch.zeros(1, dtype=torch.int64, device=dev)
         for batch in self.data_loaders["val"]:
             try:
-                latent, text_emb = self._encode(batch)
-                t = torch.randint(0, self.noise_scheduler.num_timesteps, (latent.shape[0],), device=self.device)
+                latent, text_emb, _ = self._encode(batch)          # (the reference does not check the inputs here)
+                t = torch.randint(0, self.noise_scheduler.num_timesteps, (latent.shape[0],), device=dev)
                 loss, flag = self.stepper.eval_loss(latent, text_emb, t)
-                if int(flag.item()) == 0:
-                    total += float(loss.item())
-                    nb += 1
+                good = (flag & (FLAG_PRED_BAD | FLAG_LOSS_BAD)) == 0                                  # :482-489
+                total += torch.where(good, loss, torch.zeros_like(loss))
+                nb += good.to(torch.int64)
             except Exception as e:                                 # noqa: BLE001
                 self.logger.error(f"Error in validation batch: {e}")
-        if nb == 0:
+        n = int(nb.item())
+        if n == 0:
             return {"val_loss": float("inf")}
-        self.writer.add_scalar("Diffusion Val/Loss", total / nb, epoch)
-        return {"val_loss": total / nb}
+        avg = float(total.item()) / n
+        self.writer.add_scalar("Diffusion Val/Loss", avg, epoch)
+        return {"val_loss": avg}
 
     def generate_samples(self, epoch: int, num_samples: int = 8):
-        """Monitoring only (:571-615): needs the (out-of-scope) VAE decoder; skipped when it is absent."""
-        if self.vae_decoder is None:
+        """Monitoring only (:571-615): needs the (out-of-scope) VAE decoder; skipped when it is absent; rank 0 only."""
+        if self.vae_decoder is None or not self.is_main:
             return
         batch = next(iter(self.data_loaders["val"]))
         desc = batch["full_description"][:num_samples]
@@ -403,6 +556,9 @@ class ImprovedDiffusionTrainer:
 
     # -- checkpoints (wire format of :617-655) ------------------------------------------------------------
     def save_checkpoint(self, epoch: int, is_best: bool = False):
+        if not self.is_main:                       # replicas are identical: one writer
+            return
+        self._sync_host_schedule()
         ckpt = {"epoch": epoch, "global_step": self.global_step, "unet_state_dict": self.unet.state_dict(),
                 "optimizer_state_dict": self.optimizer.state_dict(), "scheduler_state_dict": self.scheduler.state_dict(),
                 "best_val_loss": self.best_val_loss, "config": self.config}
@@ -412,11 +568,14 @@ class ImprovedDiffusionTrainer:
 
     def load_checkpoint(self, checkpoint_path: str):
         ckpt = torch.load(checkpoint_path, map_location=self.device)
-        self.current_epoch, self.global_step, self.best_val_loss = ckpt["epoch"], ckpt["global_step"], ckpt["best_val_loss"]
+        self.current_epoch, self.best_val_loss = ckpt["epoch"], ckpt["best_val_loss"]
         self.unet.load_state_dict(ckpt["unet_state_dict"])
         self.optimizer.load_state_dict(ckpt["optimizer_state_dict"])
         if self.scheduler and ckpt["scheduler_state_dict"]:
             self.scheduler.load_state_dict(ckpt["scheduler_state_dict"])
+        if not self._fused:
+            self.stepper.host_steps = int(ckpt["scheduler_state_dict"].get("last_epoch", 0)) if ckpt["scheduler_state_dict"] else 0
+        self.global_step = ckpt["global_step"]
         from .ops import WeightCache
         WeightCache.invalidate()
         self.logger.info(f"Checkpoint loaded from {checkpoint_path}")

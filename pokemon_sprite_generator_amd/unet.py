@@ -35,14 +35,24 @@ def _norm_groups(channels: int) -> int:
 
 
 class _SeedStream:
-    """Per-call dropout seeds: (torch seed, rank, running counter) -> 64-bit seed per dropout site."""
+    """Per-call dropout seeds: (torch seed, data-parallel rank, running counter) -> 64-bit seed per dropout site.
+    The rank is mixed in so that ranks seeded alike (same initial weights) still draw different masks for their
+    different batch shards; `rank` is read from the default process group unless set explicitly."""
     counter = 0
+    rank = None
+
+    @classmethod
+    def _rank(cls):
+        if cls.rank is not None:
+            return int(cls.rank)
+        d = torch.distributed
+        return d.get_rank() if (d.is_available() and d.is_initialized()) else 0
 
     @classmethod
     def next(cls):
         cls.counter += 1
         base = torch.initial_seed() & 0xFFFFFFFFFFFFFFFF
-        return (base * 0x9E3779B97F4A7C15 + cls.counter * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+        return (base * 0x9E3779B97F4A7C15 + cls._rank() * 0xBF58476D1CE4E5B9 + cls.counter * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
 
 
 def _compute_dtype_of(module, default=torch.float32):
@@ -96,7 +106,8 @@ class ResBlock(nn.Module):
 
     def nhwc(self, x, temb, pooled):
         """x [B,H,W,Cin], temb [B,128], pooled [B,256] in the compute dtype."""
-        h = ops.group_norm(x, self.norm1.weight, self.norm1.bias, self.norm1.num_groups, self.norm1.eps, silu=True)
+        # (h, x): x's second consumer below is the skip path - its gradient joins inside the GroupNorm backward
+        h, x = ops.group_norm_split(x, self.norm1.weight, self.norm1.bias, self.norm1.num_groups, self.norm1.eps, silu=True)
         # per-sample additive vector: time_proj(temb) + text_proj(pooled)  (unet.py:119-124), fused into conv1's epilogue
         ra = ops.linear(temb, self.time_proj.weight, self.time_proj.bias)
         ra = ops.linear(pooled, self.text_proj.weight, self.text_proj.bias, residual=ra)
@@ -144,12 +155,12 @@ class CrossAttentionBlock(nn.Module):
         tok = x.reshape(B, H * W, C)
         sa, ca = self.self_attn, self.cross_attn
         # self-attention (unet.py:212-221)
-        xn = ops.group_norm(tok, self.norm1.weight, self.norm1.bias, self.norm1.num_groups, self.norm1.eps)
+        xn, tok = ops.group_norm_split(tok, self.norm1.weight, self.norm1.bias, self.norm1.num_groups, self.norm1.eps)
         qkv = ops.linear(xn, sa.in_proj_weight, sa.in_proj_bias)
         o = ops.attention_self(qkv, self.num_heads, p, seeds[0])
         tok = ops.linear(o, sa.out_proj.weight, sa.out_proj.bias, residual=tok, alpha=0.7)
         # cross-attention (unet.py:229-239)
-        xn = ops.group_norm(tok, self.norm2.weight, self.norm2.bias, self.norm2.num_groups, self.norm2.eps)
+        xn, tok = ops.group_norm_split(tok, self.norm2.weight, self.norm2.bias, self.norm2.num_groups, self.norm2.eps)
         tp = ops.linear(text, self.text_proj.weight, self.text_proj.bias)
         q, kv = ops.cross_in_proj(xn, tp, ca.in_proj_weight, ca.in_proj_bias)
         o = ops.attention_cross(q, kv, self.num_heads, p, seeds[1])

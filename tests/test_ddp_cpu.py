@@ -17,7 +17,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, bucket_bytes, q):
+def _worker(rank, world, port, bucket_bytes, q, bucket_dtype="fp32"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -33,8 +33,10 @@ def _worker(rank, world, port, bucket_bytes, q):
         flat = torch.zeros(off)
         for p, o in zip(params, offsets):
             p.grad = flat[o:o + p.numel()].view_as(p)
-        red = BucketedAllReduce(flat, params, offsets, bucket_bytes=bucket_bytes, overlap=False)
+        red = BucketedAllReduce(flat, params, offsets, bucket_bytes=bucket_bytes, overlap=False,
+                                bucket_dtype=torch.bfloat16 if bucket_dtype == "bf16" else torch.float32)
         assert red.world == world
+        assert red.bytes_per_step == flat.numel() * (2 if bucket_dtype == "bf16" else 4)
         for step in range(2):
             for i, p in enumerate(params):
                 p.grad.copy_(torch.full(p.shape, float((rank + 1) * (i + 1) + step)))
@@ -49,12 +51,14 @@ def _worker(rank, world, port, bucket_bytes, q):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("bucket_dtype", ["fp32", "bf16"])
 @pytest.mark.parametrize("bucket_bytes", [1 << 10, 64 << 20])
-def test_bucketed_allreduce_gloo_world2(bucket_bytes):
+def test_bucketed_allreduce_gloo_world2(bucket_bytes, bucket_dtype):
+    """(the test values are small integers and halves: exact in bf16 too)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, bucket_bytes, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, bucket_bytes, q, bucket_dtype)) for r in range(2)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
@@ -76,3 +80,65 @@ def test_batch_sharding_is_exact_for_mean_losses():
     full = torch.autograd.grad(torch.nn.functional.smooth_l1_loss(x @ w.t(), y, beta=0.1), w)[0]
     parts = [torch.autograd.grad(torch.nn.functional.smooth_l1_loss(x[i:i + 4] @ w.t(), y[i:i + 4], beta=0.1), w)[0] for i in (0, 4)]
     assert torch.allclose(full, (parts[0] + parts[1]) / 2, atol=1e-6)
+
+
+def test_sharded_loader_slices_every_global_batch():
+    """ddp.ShardedLoader: rank r keeps rows [r*n/N, (r+1)*n/N) of every batch the wrapped loader yields (dict batches
+    of tensors and string lists, like the reference's `create_data_loaders`); ragged tails are trimmed equally."""
+    from pokemon_sprite_generator_amd.ddp import ShardedLoader
+    batches = [{"image": torch.arange(8 * 3).reshape(8, 3), "full_description": [f"d{i}" for i in range(8)], "meta": 5},
+               {"image": torch.arange(5 * 3).reshape(5, 3), "full_description": [f"e{i}" for i in range(5)], "meta": 6},
+               {"image": torch.arange(1 * 3).reshape(1, 3), "full_description": ["f0"], "meta": 7}]
+    got = [list(ShardedLoader(batches, r, 2)) for r in range(2)]
+    assert len(got[0]) == len(got[1]) == 2                      # the 1-sample batch is dropped on every rank
+    assert len(ShardedLoader(batches, 0, 2)) == 3               # (len is the wrapped loader's: the schedule length)
+    for r in range(2):
+        assert torch.equal(got[r][0]["image"], batches[0]["image"][4 * r:4 * r + 4])
+        assert got[r][0]["full_description"] == [f"d{i}" for i in range(4 * r, 4 * r + 4)]
+        assert got[r][0]["meta"] == 5
+        assert torch.equal(got[r][1]["image"], batches[1]["image"][2 * r:2 * r + 2])     # 5 -> 2 + 2, last one trimmed
+        assert got[r][1]["full_description"] == [f"e{i}" for i in range(2 * r, 2 * r + 2)]
+    tup = [(torch.arange(6), torch.arange(6) * 2)]
+    a, b = list(ShardedLoader(tup, 1, 3))[0]
+    assert a.tolist() == [2, 3] and b.tolist() == [4, 6]
+
+
+def test_schedule_tables_reproduce_onecycle():
+    """trainer.schedule_tables: entry k = (lr, beta1) the reference's scheduler holds after k scheduler.step() calls
+    (OneCycleLR cycles Adam's beta1 between 0.95 and 0.85, improved_diffusion_trainer.py:313-319)."""
+    from pokemon_sprite_generator_amd.trainer import schedule_tables
+    mk = lambda opt: torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=3e-4, total_steps=20, pct_start=0.1, anneal_strategy="cos")
+    lrs, b1s = schedule_tables(mk, 3e-4, (0.9, 0.999), 20)
+    opt = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=3e-4, betas=(0.9, 0.999))
+    sch = mk(opt)
+    assert len(lrs) == 20
+    for k in range(20):
+        assert lrs[k] == opt.param_groups[0]["lr"] and b1s[k] == opt.param_groups[0]["betas"][0], k
+        if k < 19:
+            opt.step(); sch.step()
+    assert abs(lrs[0] - 3e-4 / 25) < 1e-12 and abs(b1s[0] - 0.95) < 1e-12 and abs(max(lrs) - 3e-4) < 1e-12 and abs(min(b1s) - 0.85) < 1e-12
+    lrs, b1s = schedule_tables(lambda o: torch.optim.lr_scheduler.ConstantLR(o, factor=1.0), 1e-4, (0.9, 0.999), 1)
+    assert lrs == [1e-4] and b1s == [0.9]
+
+
+def test_arena_displacement_is_loud():
+    """A second ParamArena / GradArena over the same parameters displaces the first: the older ones raise instead of
+    running on re-bound storage / cleared gradient sinks; unrelated arenas are untouched."""
+    from pokemon_sprite_generator_amd.optim import ArenaDisplaced, GradArena, ParamArena
+    from pokemon_sprite_generator_amd.ops import GradSink
+    ps = [torch.nn.Parameter(torch.randn(4, 3, 3, 3)), torch.nn.Parameter(torch.randn(7))]
+    other = [torch.nn.Parameter(torch.randn(5))]
+    pa1, ga1, gb = ParamArena(ps), GradArena(ps), GradArena(other)
+    w = ps[0].detach().clone()
+    pa2, ga2 = ParamArena(ps), GradArena(ps)
+    assert torch.equal(ps[0].detach(), w)                        # values survive the re-binding
+    assert ps[0].data_ptr() >= pa2.flat.data_ptr() and ps[0].data_ptr() < pa2.flat.data_ptr() + pa2.flat.numel() * 4
+    with pytest.raises(ArenaDisplaced):
+        pa1.check_alive()
+    with pytest.raises(ArenaDisplaced):
+        ga1.zero()
+    ga2.zero(); gb.zero()                                        # the newest and the unrelated one still work
+    assert GradSink.get(ps[0]).owner is ga2 and GradSink.get(other[0]).owner is gb
+    ga2.release()
+    assert GradSink.get(ps[0]) is None and GradSink.get(other[0]) is not None
+    gb.release()

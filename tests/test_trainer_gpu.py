@@ -1,0 +1,188 @@
+"""-m gpu: the drop-in boundary the north-star names — `ImprovedDiffusionTrainer(config, ckpt, name)` as
+train_3stage.py:130-140 constructs and drives it (reference: improved_diffusion_trainer.py:82-126, 335-445, 617-692).
+
+Out-of-scope collaborators (BERT text encoder, frozen VAE encoder, data loaders) are stubs injected through
+`components=`; everything the class itself does runs for real on the full-width U-Net: train() for 2 epochs, the
+reference's bad-batch semantics (a NaN batch does not advance optimizer / scheduler / global_step and is excluded from
+the epoch mean; a fallback-rescued batch trains), checkpoint save -> load into a fresh trainer -> identical next step,
+and the checkpoint's 'unet_state_dict' loading into plain torch.nn containers in the reference layout."""
+import math
+
+import pytest
+import torch
+
+from oracle import hashgen, unet_oracle as O
+from tests.util import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+HEADS = 4            # the reference CLI's real head count (improved_diffusion_trainer.py:215)
+
+
+def _config(tmp, epochs=2):
+    # keys of config/train_config.yaml that stage 2 reads; scheduler "cosine" exercises OneCycleLR (:313-319)
+    return {
+        "experiment_dir": str(tmp),
+        "model": {"bert_model": "stub", "text_embedding_dim": 256, "latent_dim": 8, "num_timesteps": 1000, "beta_start": 0.0001,
+                  "beta_end": 0.02},
+        "data": {"csv_path": "-", "image_dir": "-", "batch_size": 4, "image_size": 215, "num_workers": 0, "pin_memory": False,
+                 "val_split": 0.15, "test_split": 0.05},
+        "training": {"diffusion_epochs": epochs, "log_every": 1, "save_every": 1, "sample_every": 1000},
+        "optimization": {"optimizer": "adamw", "learning_rate": 3e-4, "weight_decay": 0.01, "max_grad_norm": 1.0, "scheduler": "cosine"},
+    }
+
+
+class _TextStub:
+    """descriptions -> [B, 32, 256] (deterministic in the strings)."""
+
+    def __call__(self, descriptions):
+        rows = [hashgen.uniform((32, 256), 77, hashgen.name_id(d)) * math.sqrt(3.0) for d in descriptions]
+        return torch.stack(rows).to(DEV)
+
+
+class _VAEStub:
+    """images [B,3,16,16] -> (latent, mu, logvar) like VAEEncoder.forward (vae_decoder.py:68-125); an image whose first
+    pixel is negative yields a NaN latent (the trainer must skip that batch, :359)."""
+
+    def __call__(self, images):
+        B = images.shape[0]
+        lat = torch.stack([hashgen.uniform((8, 27, 27), 78, int(images[i, 0, 0, 1].item() * 1000) % 100000) * 2.0 for i in range(B)]).to(DEV)
+        bad = images[:, 0, 0, 0] < 0
+        lat[bad] = float("nan")
+        return lat, lat, lat
+
+
+def _loaders(nan_batch=1):
+    def batch(i, bad=False):
+        img = torch.rand(4, 3, 16, 16, generator=torch.Generator().manual_seed(100 + i))
+        if bad:
+            img[0, 0, 0, 0] = -1.0
+        return {"image": img, "full_description": [f"pokemon {i}-{j}" for j in range(4)]}
+    train = [batch(i, bad=(i == nan_batch)) for i in range(3)]
+    return {"train": train, "val": [batch(10)], "test": []}
+
+
+def _trainer(psg, tmp, name, nan_batch=1):
+    comps = {"text_encoder": _TextStub(), "vae_encoder": _VAEStub(), "data_loaders": _loaders(nan_batch)}
+    return psg.ImprovedDiffusionTrainer(_config(tmp), "unused.pth", name, components=comps, compute_dtype=torch.bfloat16)
+
+
+@pytest.fixture(scope="module")
+def psg():
+    import pokemon_sprite_generator_amd as m
+    from pokemon_sprite_generator_amd import _lib
+    _lib.init(0)
+    return m
+
+
+def test_trainer_dropin_train_checkpoint_resume(psg, tmp_path, monkeypatch):
+    import pokemon_sprite_generator_amd.unet as U
+    torch.manual_seed(0)
+    tr = _trainer(psg, tmp_path, "a")
+    assert tr.unet.enc_block1[0].attn_block.num_heads == HEADS          # config default num_heads=4 (:215)
+    assert tr.global_step == 0 and tr.current_epoch == 0
+    p0 = tr.stepper.params.flat.clone()
+    tr.train()                                                            # 2 epochs x 3 batches, batch 1 of each is NaN
+    # ---- the reference's `continue` semantics (:353-393): 4 optimizer steps, 4 scheduler steps, global_step 4
+    assert tr.optimizer.steps_done() == 4
+    assert tr.global_step == 4
+    assert not torch.equal(tr.stepper.params.flat, p0)
+    tr._sync_host_schedule()
+    ref_opt = torch.optim.AdamW([torch.nn.Parameter(torch.zeros(1))], lr=3e-4, betas=(0.9, 0.999))
+    ref_sch = torch.optim.lr_scheduler.OneCycleLR(ref_opt, max_lr=3e-4, total_steps=6, pct_start=0.1, anneal_strategy="cos")
+    for _ in range(4):
+        ref_opt.step(); ref_sch.step()
+    assert tr.scheduler.last_epoch == 4 == ref_sch.last_epoch
+    assert abs(tr.optimizer.param_groups[0]["lr"] - ref_opt.param_groups[0]["lr"]) < 1e-12
+    assert abs(tr.optimizer.param_groups[0]["betas"][0] - ref_opt.param_groups[0]["betas"][0]) < 1e-7   # OneCycle cycles beta1
+    assert (tr.checkpoint_dir / "diffusion_best_model.pth").exists()      # epoch 0 was a "best" (:680-685)
+    assert (tr.log_dir / "diffusion_training.log").exists()
+
+    # ---- epoch mean excludes the skipped batch, counts it as neither trained nor NaN-prediction
+    m = tr.train_epoch(99)
+    assert math.isfinite(m["train_loss"]) and m["train_loss"] > 0
+    assert tr.optimizer.steps_done() == 6
+
+    # ---- skip / no-skip decisions of one step, all on the device
+    lat = (hashgen.uniform((2, 8, 27, 27), 5, 1) * 2).to(DEV)
+    txt = (hashgen.uniform((2, 32, 256), 5, 2)).to(DEV)
+    t = torch.tensor([100, 900], device=DEV)
+    nz = hashgen.uniform((2, 8, 27, 27), 5, 3).to(DEV)
+    out = tr.train_step(lat, txt, t, noise=nz)
+    assert int(out["nan_flag"].item()) == 0 and tr.optimizer.steps_done() == 7
+    before = tr.stepper.params.flat.clone()
+    out = tr.train_step(lat * float("nan"), txt, t, noise=nz)            # NaN latent: the fallback is NaN too -> skip (:376)
+    assert int(out["nan_flag"].item()) & 1 and tr.optimizer.steps_done() == 7
+    out = tr.train_step(lat, txt, torch.tensor([100, 1000], device=DEV), noise=nz)   # timestep out of range -> skip
+    assert int(out["nan_flag"].item()) & 2 and tr.optimizer.steps_done() == 7
+    out = tr.train_step(lat, txt, t, noise=nz, pre_flag=torch.tensor([32], device=DEV))   # caller's input check (:353,359)
+    assert int(out["nan_flag"].item()) == 32 and tr.optimizer.steps_done() == 7
+    assert torch.equal(tr.stepper.params.flat, before), "a skipped step must leave the parameters untouched"
+    # a batch rescued by add_noise's fallback (:61-63) carries bit 16 only and TRAINS (kernel-level rescue itself:
+    # tests/test_kernels_gpu.py::test_noise_add_bit_exact; with the trainer's clamp a finite batch cannot overflow)
+    out = tr.train_step(lat, txt, t, noise=nz, pre_flag=torch.tensor([16], device=DEV))
+    assert int(out["nan_flag"].item()) == 16 and tr.optimizer.steps_done() == 8
+    assert not torch.equal(tr.stepper.params.flat, before)
+
+    # ---- checkpoint round trip into a fresh trainer (:617-655) and an identical next step
+    tr.best_val_loss = 0.123
+    tr.save_checkpoint(1, is_best=True)
+    path = tr.checkpoint_dir / "diffusion_best_model.pth"
+    ck = torch.load(path, map_location="cpu")
+    assert set(ck) == {"epoch", "global_step", "unet_state_dict", "optimizer_state_dict", "scheduler_state_dict", "best_val_loss", "config"}
+    assert ck["global_step"] == 8 and len(ck["unet_state_dict"]) == 479
+    assert float(ck["optimizer_state_dict"]["state"][0]["step"]) == 8.0
+    assert ck["scheduler_state_dict"]["last_epoch"] == 8
+    torch.manual_seed(1)
+    tr2 = _trainer(psg, tmp_path, "b")
+    tr2.load_checkpoint(str(path))
+    assert tr2.global_step == 8 and tr2.current_epoch == 1 and tr2.best_val_loss == 0.123
+    assert tr2.optimizer.steps_done() == 8
+    assert torch.equal(tr2.stepper.params.flat, tr.stepper.params.flat)
+    assert torch.equal(tr2.optimizer._m, tr.optimizer._m) and torch.equal(tr2.optimizer._v, tr.optimizer._v)
+    monkeypatch.setattr(U, "ATTN_DROPOUT", 0.0)                           # dropout seeds are per call: off for the A/B step
+    o1 = tr.train_step(lat, txt, t, noise=nz)
+    o2 = tr2.train_step(lat, txt, t, noise=nz)
+    assert float(o1["loss"].item()) == float(o2["loss"].item())
+    assert torch.equal(tr2.stepper.params.flat, tr.stepper.params.flat), "resumed trainer must take the identical step"
+    tr2._sync_host_schedule()
+    assert tr2.scheduler.last_epoch == 9
+
+    # ---- the checkpoint loads into plain torch.nn containers in the reference layout (contiguous OIHW, 479 keys)
+    plain = psg.UNet(8, 256, 128, HEADS)                                  # CPU, untouched by any arena
+    missing = plain.load_state_dict(ck["unet_state_dict"])
+    assert not missing.missing_keys and not missing.unexpected_keys
+    w = plain.enc_block1[0].res_block.conv1.weight
+    assert w.is_contiguous() and tuple(w.shape) == (640, 640, 3, 3)
+    tr.optimizer.load_state_dict(tr.optimizer.state_dict())              # state_dict round trip on the live optimizer
+    sd = {k: v.float() for k, v in ck["unet_state_dict"].items()}
+    x, tt, text = hashgen.unet_inputs(1, 31)
+    from pokemon_sprite_generator_amd import ops
+    with torch.no_grad():
+        tr2.unet.load_state_dict(ck["unet_state_dict"])                   # in-place load keeps the arena binding
+        w2 = tr2.unet.enc_block1[0].res_block.conv1.weight
+        assert ops.weight_layout(w2.detach()) == ops.W_OHWI               # (memory order OHWI inside the arena ...)
+        assert torch.equal(w2.detach().cpu().contiguous(), ck["unet_state_dict"]["enc_block1.0.res_block.conv1.weight"])   # ... same values
+        ref = O.unet_forward(sd, x, tt, text, HEADS)
+        tr2.unet.eval()
+        got = tr2.unet(x.to(DEV), tt.to(DEV), text.to(DEV)).cpu()
+    assert rel_l2(got, ref) < 3e-2                                        # bf16 compute vs the fp32 oracle on the saved weights
+
+
+def test_second_stepper_displaces_the_first(psg):
+    """One stepper per model: building another over the same parameters makes the older one refuse to step (it used to
+    keep running on registrations the newer one had silently cleared)."""
+    from pokemon_sprite_generator_amd.optim import ArenaDisplaced
+    blk = torch.nn.Sequential(torch.nn.Conv2d(8, 16, 3, padding=1)).to(DEV)
+    blk.compute_dtype = torch.float32
+    s1 = psg.DiffusionStepper(blk, psg.NoiseScheduler(), distributed=False)
+    s2 = psg.DiffusionStepper(blk, psg.NoiseScheduler(), distributed=False)
+    with pytest.raises(ArenaDisplaced):
+        s1.arena.zero()
+    with pytest.raises(ArenaDisplaced):
+        s1.optimizer.step()
+    s2.arena.zero()                      # the newest owns the sinks
+    s2.arena.finalize()
+    s2.optimizer.step(normsq=s2.arena.grad_norm_sq(), max_norm=1.0, skip_flag=s2.flag)
+    assert s2.optimizer.steps_done() == 1
+    s2.close()

@@ -202,6 +202,141 @@ def test_train_step_golden(psg, golden, full_unets):
     assert int(st.flag.item()) == 0
 
 
+def test_train_step_golden_bf16(psg, golden, full_unets):
+    """The BENCHMARKED arithmetic (bf16 MFMA, fp32 accumulate / master / gradients) against the same reference fixture as
+    the fp32 leg above: eps-hat, loss, the global gradient norm, all 478 per-parameter gradient norms and the sampled
+    gradient slices.  Bars (bf16 has 8 significant bits; stated, not hidden): eps-hat MSE < 1e-3 and rel-L2 < 3e-2; loss
+    rel < 2e-2; global |g| rel < 3e-2; the VECTOR of per-parameter norms rel-L2 < 3e-2 and every single one within 10 %;
+    every sampled slice rel-L2 < 6e-2 (per-element noise of a bf16 chain ~ 1-3 %)."""
+    g = golden("unet_full.npz")
+    name, mode, b, ts, heads = cases.TRAIN_CASE
+    u, _ = full_unets(mode, heads)
+    u.set_compute_dtype(torch.bfloat16)
+    from pokemon_sprite_generator_amd.ops import WeightCache
+    WeightCache.clear()
+    try:
+        x, t, text = hashgen.unet_inputs(b, cases.INPUT_SEED, t=ts)
+        noise = hashgen.uniform(x.shape, cases.INPUT_SEED, hashgen.name_id("train.noise")) * math.sqrt(3.0)
+        st = psg.DiffusionStepper(u, _fixture_scheduler(psg, golden), lr=0.0, weight_decay=0.0, max_grad_norm=1.0, distributed=False)
+        u.eval()                                           # dropout off, like the fixture
+        st.flag.zero_()
+        noisy = st.noise_scheduler.add_noise((x * 2.0).to(DEV), noise.to(DEV), t.to(DEV), clamp=True, flag=st.flag)
+        st.arena.zero()
+        eps = u(noisy, t.to(DEV), text.to(DEV))
+        loss, dpred = st.smooth_l1(eps, noise.to(DEV))
+        eps.backward(dpred)
+        st.arena.finalize()
+        gn = float(st.arena.grad_norm_sq().sqrt().item())
+        ref_eps = torch.from_numpy(g[name + "_eps"])
+        mse, r_eps = float(((eps.detach().cpu() - ref_eps) ** 2).mean()), rel_l2(eps, ref_eps)
+        l_rel = abs(float(loss.item()) - float(g[name + "_loss"][0])) / float(g[name + "_loss"][0])
+        gn_rel = abs(gn - float(g[name + "_grad_norm"][0])) / float(g[name + "_grad_norm"][0])
+        norms = np.array([float(p.grad.double().norm()) for p in u.parameters()])
+        ref = g[name + "_param_grad_norms"]
+        vec_rel = float(np.linalg.norm(norms - ref) / np.linalg.norm(ref))
+        each = np.abs(norms - ref) / (ref + 1e-12)
+        named = dict(u.named_parameters())
+        worst_slice = 0.0
+        for k in [kk[len(name) + 3:-2] for kk in g if kk.startswith(name + "_g_") and kk.endswith("_d")]:
+            d, s_ref = g[f"{name}_g_{k}_d"], g[f"{name}_g_{k}_s"]
+            sample = named[k].grad.detach().reshape(-1).double().cpu()[::int(d[2])].float().numpy()
+            assert sample.shape == s_ref.shape, k
+            worst_slice = max(worst_slice, float(np.linalg.norm(sample - s_ref) / (np.linalg.norm(s_ref) + 1e-30)))
+        print(f"bf16 train step vs reference fixture: eps MSE {mse:.2e} rel-L2 {r_eps:.2e}; loss rel {l_rel:.2e}; |g| rel {gn_rel:.2e}; "
+              f"per-param norm vector rel-L2 {vec_rel:.2e}, worst single {each.max():.2e} (#{each.argmax()}); worst slice rel-L2 {worst_slice:.2e}")
+        assert mse < 1e-3 and r_eps < 3e-2
+        assert l_rel < 2e-2 and gn_rel < 3e-2
+        assert vec_rel < 3e-2 and each.max() < 0.10, f"per-parameter grad norms: vector {vec_rel:.2e}, worst {each.max():.2e} at #{each.argmax()}"
+        assert worst_slice < 6e-2
+        assert int(st.flag.item()) == 0
+    finally:
+        u.set_compute_dtype(torch.float32)
+        WeightCache.clear()
+
+
+def test_wgrad_side_stream_is_bitwise_neutral(psg):
+    """Batch 64, bf16, full width (a size where the weight-gradient GEMMs really overlap the data-gradient chain): the
+    gradient arena must be bit-identical with the second stream on and off.  Guards the hazard that `d_res = dy` handed
+    back to autograd is accumulated into in place on the main stream while the side-stream wgrad still reads it
+    (ops.SideStream._pending).  Also: the U-Net path makes no hidden layout copies (ops.RowCopies)."""
+    from pokemon_sprite_generator_amd import ops
+    torch.manual_seed(3)
+    u = psg.UNet(compute_dtype=torch.bfloat16).to(DEV)
+    st = psg.DiffusionStepper(u, psg.NoiseScheduler(), lr=0.0, weight_decay=0.0, distributed=False)
+    g = torch.Generator(device=DEV).manual_seed(5)
+    B = 64
+    lat, txt = torch.randn(B, 8, 27, 27, device=DEV, generator=g), torch.randn(B, 32, 256, device=DEV, generator=g)
+    t = torch.randint(0, 1000, (B,), device=DEV, generator=g)
+    nz = torch.randn(B, 8, 27, 27, device=DEV, generator=g)
+    saved = ops.SideStream.enabled
+    flats = {}
+    try:
+        for on in (True, False, True):
+            ops.SideStream.enabled = on
+            psg.unet._SeedStream.counter = 0               # same dropout masks in every run
+            ops.RowCopies.count = 0
+            r = st.train_step(lat, txt, t, nz)
+            torch.cuda.synchronize()
+            assert int(r["nan_flag"].item()) == 0
+            assert ops.RowCopies.count == 0, f"{ops.RowCopies.count} hidden layout copies in one train step"
+            flats.setdefault(on, []).append(st.arena.flat.clone())
+    finally:
+        ops.SideStream.enabled = saved
+    assert torch.equal(flats[True][0], flats[True][1]), "side-stream run is not reproducible"
+    assert torch.equal(flats[True][0], flats[False][0]), "gradients differ between PSG_WGRAD_STREAM=1 and 0"
+    st.close()
+
+
+def test_sampler_full_schedule_prefix_n64(psg):
+    """BASELINE configs[4] shape on one GPU: 64 samples, the 1000-step schedule (fast_sampling=False), first 50 steps
+    (t = 999..950), bf16.  Properties: the hipGraph replay equals the eager loop bit for bit, every x_t is finite, the
+    timestep sequence is exactly the reference's reversed(range(1000)) (:531-534), and one step of the chain equals
+    c1[t]*(x - c2[t]*eps) + sqrt(beta_t)*z evaluated with the reference's own torch expression (:554-563) bit for bit."""
+    torch.manual_seed(4)
+    u = psg.UNet(compute_dtype=torch.bfloat16).to(DEV).eval()
+    sch = psg.NoiseScheduler()
+    st = psg.DiffusionStepper(u, sch, lr=0.0, distributed=False)
+    n, K = 64, 50
+    text = torch.randn(n, 32, 256, device=DEV)
+    zs = {}
+
+    def noise_fn(i, shape):
+        if i not in zs:
+            zs[i] = torch.randn(shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(1000 + i))
+        return zs[i]
+
+    seen = []
+    orig = psg.DiffusionStepper._sample_set
+
+    def spy(t, i, tv, t_dev, z, rnd, x):
+        seen.append(t)
+        return orig(t, i, tv, t_dev, z, rnd, x)
+    psg.DiffusionStepper._sample_set = staticmethod(spy)
+    try:
+        tr_g, tr_e = [], []
+        xg = st.sample(text, n, fast_sampling=False, noise_fn=noise_fn, trace=tr_g, use_graph=True, max_steps=K)
+        n_set_graph = len(seen)
+        xe = st.sample(text, n, fast_sampling=False, noise_fn=noise_fn, trace=tr_e, use_graph=False, max_steps=K)
+    finally:
+        psg.DiffusionStepper._sample_set = staticmethod(orig)
+    assert len(tr_g) == len(tr_e) == K
+    assert seen[n_set_graph:] == list(range(999, 999 - K, -1))               # eager: one set per step, t = 999, 998, ...
+    assert sorted(set(seen[:n_set_graph]), reverse=True) == list(range(999, 999 - K, -1))
+    assert torch.equal(xg, xe)
+    for a, b in zip(tr_g, tr_e):
+        assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+    # one link of the chain, recomputed: step index 10 (t = 989)
+    i, t = 10, 989
+    with torch.no_grad():
+        eps = u(tr_e[i - 1], torch.full((n,), t, device=DEV, dtype=torch.long), text)
+    tables = {k: getattr(sch.to("cpu"), k) for k in ("alphas", "alphas_cumprod", "betas")}
+    sch.to(DEV)
+    c1, c2, sg = O.ddpm_step_coeffs(tables, t)
+    want = c1 * (tr_e[i - 1].cpu() - c2 * eps.cpu()) + sg * zs[i].cpu()
+    assert torch.equal(tr_e[i].cpu(), want), "ddpm update / timestep lookup is not bit-exact"
+    st.close()
+
+
 def test_train_step_updates_and_decreases_loss(psg):
     """bf16 full train_step facade: 8 steps on one fixed batch must reduce the loss; flags clean."""
     torch.manual_seed(0)
