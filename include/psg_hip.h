@@ -165,6 +165,10 @@ int64_t psg_groupnorm_bwd_workspace_bytes(int B, int C);
  * on the forward INPUT grid [Ho,Wo]); with a dgrad-prepared weight this is
  * conv2d's dgrad for any stride.
  * ------------------------------------------------------------------------- */
+/* PSG_CONV_SAVE_DACT (forward form): `preact` receives the epilogue's DERIVATIVE d = act'(u) * mask/(1-p) instead of
+ *   the pre-activation u, so that backward multiplies by a loaded value instead of re-evaluating erf/exp and the mask.
+ * PSG_CONV_DACT_MUL (backward form): `dact_u` holds that saved derivative: value *= dact_u (no act', drop_p must be 0). */
+enum psg_conv_flags { PSG_CONV_SAVE_DACT = 1, PSG_CONV_DACT_MUL = 2 };
 typedef struct psg_conv_desc {
     int32_t dtype;               /* psg_dtype of x, w, y, rowadd, residual, preact, dact_u */
     int32_t B, Hi, Wi, Cin;      /* gather source x: [B, Hi, Wi, Cin] */
@@ -174,6 +178,7 @@ typedef struct psg_conv_desc {
     int32_t act;                 /* psg_act applied to (acc + bias + rowadd) */
     float alpha;                 /* scale of the activated value (gates 0.7/0.8/0.6: unet.py:220,238,250) */
     float drop_p;                /* dropout probability on the activated value (0 = off) */
+    int32_t flags;               /* psg_conv_flags (0 = none) */
     uint64_t drop_seed;          /* mask = hash(seed, m*Cout+n) — regenerated in backward */
     int64_t ldx, ldy, ld_rowadd, ld_residual, ld_preact, ld_dact;
     int64_t ldw;                 /* row stride of w in elements; 0 = Kpad (a column slice of a wider prepared

@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("PSG_LIB_PATH") or os.path.join(_HERE, "libpsg_hip.so"
 
 PSG_F32, PSG_BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
+CONV_SAVE_DACT, CONV_DACT_MUL = 1, 2          # enum psg_conv_flags
 # enum psg_flag: bits of the per-step NaN/Inf flag word
 FLAG_NOISY_BAD, FLAG_T_RANGE, FLAG_PRED_BAD, FLAG_LOSS_BAD, FLAG_FALLBACK, FLAG_INPUT_BAD, FLAG_SKIP_MASK = 1, 2, 4, 8, 16, 32, 47
 
@@ -26,7 +27,7 @@ class ConvDesc(C.Structure):
         ("Ho", C.c_int32), ("Wo", C.c_int32), ("Cout", C.c_int32),
         ("ksize", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
         ("transposed", C.c_int32), ("act", C.c_int32),
-        ("alpha", C.c_float), ("drop_p", C.c_float), ("drop_seed", C.c_uint64),
+        ("alpha", C.c_float), ("drop_p", C.c_float), ("flags", C.c_int32), ("drop_seed", C.c_uint64),
         ("ldx", C.c_int64), ("ldy", C.c_int64), ("ld_rowadd", C.c_int64), ("ld_residual", C.c_int64),
         ("ld_preact", C.c_int64), ("ld_dact", C.c_int64), ("ldw", C.c_int64),
         ("x", c_void_p), ("w", c_void_p), ("y", c_void_p), ("bias", c_void_p), ("rowadd", c_void_p),

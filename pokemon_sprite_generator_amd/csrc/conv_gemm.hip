@@ -30,6 +30,7 @@ struct ConvP {
     int M, taps, cpt, KT, Kpad, fast, tpt;
     int mtiles, ntiles;
     int act; float alpha;
+    int flags;                     // PSG_CONV_SAVE_DACT / PSG_CONV_DACT_MUL
     uint32_t drop_thresh; float drop_scale; uint64_t drop_seed;
     uint32_t x_bytes, w_bytes;     // extents for the bounds-checked buffer loads
     // MODE 3 (one parity class of a stride-2 data gradient): result pixels (sub_h0 + 2i, sub_w0 + 2j), i < sub_nH,
@@ -84,23 +85,39 @@ __device__ __forceinline__ void conv_out_row(const ConvP& p, int mt, int& m, int
 // without (fwd vs dgrad of the same GEMM).
 template <typename T>
 __device__ __forceinline__ void conv_emit(const ConvP& p, int m, int n, f32x4 v, f32x4 bias4, f32x4 ra4, f32x4 aux4) {
-    // aux4: the residual, or (backward form, dact_u set - the two are mutually exclusive) the saved pre-activation u
+    // aux4: the residual, or (backward form, dact_u set - the two are mutually exclusive) the saved pre-activation u /
+    // the saved epilogue derivative
+    constexpr bool FAST = sizeof(T) == 2;                  // bf16 compute: bf16-grade GELU (exact fp32 path keeps erff)
     T* yg = reinterpret_cast<T*>(p.y);
     T* preg = reinterpret_cast<T*>(p.preact);
     v += bias4 + ra4;
-    if (preg) store4<T>(preg + (int64_t)m * p.ldpre + n, v);
-    if (p.dact_u) {     // backward form: multiply by act'(u) of the saved pre-activation
+    const bool save_d = (p.flags & PSG_CONV_SAVE_DACT) != 0;
+    f32x4 d = {1.f, 1.f, 1.f, 1.f};                        // d(epilogue value)/d(accumulator), apart from alpha
+    if (preg && !save_d) store4<T>(preg + (int64_t)m * p.ldpre + n, v);
+    if (p.dact_u) {
+        if (p.flags & PSG_CONV_DACT_MUL) v *= aux4;       // backward form, derivative saved by the forward launch
+        else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= act_grad(aux4[e], p.act);
+            for (int e = 0; e < 4; ++e) v[e] *= act_grad(aux4[e], p.act);
+        }
     } else if (p.act != PSG_ACT_NONE) {
+        if (save_d || FAST) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = act_f(v[e], p.act);
+            for (int e = 0; e < 4; ++e) { float y, dy; act_both<FAST>(v[e], p.act, y, dy); v[e] = y; d[e] = dy; }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = act_f(v[e], p.act);
+        }
     }
     if (p.drop_thresh) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
-            v[e] = drop_keep(p.drop_seed, (uint64_t)m * p.N + n + e, p.drop_thresh) ? v[e] * p.drop_scale : 0.f;
+        for (int e = 0; e < 4; ++e) {
+            const bool keep = drop_keep(p.drop_seed, (uint64_t)m * p.N + n + e, p.drop_thresh);
+            v[e] = keep ? v[e] * p.drop_scale : 0.f;
+            d[e] = keep ? d[e] * p.drop_scale : 0.f;
+        }
     }
+    if (preg && save_d) store4<T>(preg + (int64_t)m * p.ldpre + n, d);
     v *= p.alpha;
     if (!p.dact_u) v += aux4;
     store4<T>(yg + (int64_t)m * p.ldy + n, v);
@@ -523,6 +540,10 @@ int psg_conv_fwd(const psg_conv_desc* d, psg_stream_t stream) {
     PSG_REQUIRE(!d->dact_u || (aligned16(d->dact_u) && d->ld_dact % 4 == 0), PSG_ERR_ALIGN, "conv_fwd: dact_u alignment");
     PSG_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, PSG_ERR_ARG, "conv_fwd: drop_p %f", d->drop_p);
     PSG_REQUIRE(!(d->residual && d->dact_u), PSG_ERR_ARG, "conv_fwd: residual and dact_u are mutually exclusive");
+    PSG_REQUIRE((d->flags & ~(PSG_CONV_SAVE_DACT | PSG_CONV_DACT_MUL)) == 0, PSG_ERR_ARG, "conv_fwd: unknown flags 0x%x", d->flags);
+    PSG_REQUIRE(!(d->flags & PSG_CONV_SAVE_DACT) || (d->preact && !d->dact_u), PSG_ERR_ARG, "conv_fwd: SAVE_DACT needs preact (forward form)");
+    PSG_REQUIRE(!(d->flags & PSG_CONV_DACT_MUL) || (d->dact_u && d->drop_p == 0.f), PSG_ERR_ARG,
+                "conv_fwd: DACT_MUL needs dact_u and drop_p = 0 (the saved derivative already carries the mask)");
     // geometry consistency
     if (!d->transposed) {
         PSG_REQUIRE(d->Ho == (d->Hi + 2 * d->pad - d->ksize) / d->stride + 1 && d->Wo == (d->Wi + 2 * d->pad - d->ksize) / d->stride + 1,
@@ -546,7 +567,7 @@ int psg_conv_fwd(const psg_conv_desc* d, psg_stream_t stream) {
     p.ks = d->ksize; p.stride = d->stride; p.pad = d->pad; p.transposed = d->transposed;
     p.M = (int)M; p.taps = taps; p.cpt = d->Cin / CH; p.Kpad = (int)Kpad; p.KT = (int)(Kpad / (8 * CH));
     p.fast = (p.cpt % 8 == 0) ? 1 : 0; p.tpt = p.fast ? p.cpt / 8 : 1;
-    p.act = d->act; p.alpha = d->alpha;
+    p.act = d->act; p.alpha = d->alpha; p.flags = d->flags;
     p.drop_thresh = d->drop_p > 0.f ? drop_thresh(d->drop_p) : 0u;
     p.drop_scale = d->drop_p > 0.f ? 1.0f / (1.0f - d->drop_p) : 1.0f;
     p.drop_seed = d->drop_seed;

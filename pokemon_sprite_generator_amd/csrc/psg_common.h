@@ -90,6 +90,33 @@ __device__ __forceinline__ float gelu_grad(float x) {
     float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
     return cdf + x * pdf;
 }
+// GELU and its derivative from ONE exponential: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7 absolute - far below a
+// bf16 ulp; the exact-fp32 path keeps erff), whose exp(-z^2) with z = x/sqrt(2) is also the Gaussian of the derivative.
+// ~16 VALU operations instead of ~60 for erff + expf: the GELU epilogues of the FFN GEMMs were as long as their K loops.
+__device__ __forceinline__ void gelu_both_fast(float x, float& y, float& dy) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    const float e = __expf(-z * z);
+    const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+    const float h = 0.5f - 0.5f * poly * e;                      // 0.5 * erf(|z|)
+    const float cdf = x >= 0.f ? 0.5f + h : 0.5f - h;
+    y = x * cdf;
+    dy = cdf + x * 0.39894228040143268f * e;
+}
+// (value, derivative) of an activation; FAST selects the bf16-grade GELU above
+template <bool FAST>
+__device__ __forceinline__ void act_both(float x, int act, float& y, float& dy) {
+    if (act == PSG_ACT_GELU) {
+        if (FAST) { gelu_both_fast(x, y, dy); return; }
+        const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+        y = x * cdf;
+        dy = cdf + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+    } else if (act == PSG_ACT_SILU) {
+        const float s = sigmoidf_(x);
+        y = x * s;
+        dy = s * (1.0f + x * (1.0f - s));
+    } else { y = x; dy = 1.0f; }
+}
 __device__ __forceinline__ float act_f(float x, int act) {
     return act == PSG_ACT_SILU ? silu_f(x) : (act == PSG_ACT_GELU ? gelu_f(x) : x);
 }

@@ -224,13 +224,13 @@ class GradSink:
 
 
 def _conv_launch(lib, dtype, x, ldx, w, ldw, y, ldy, geom, Cin, Cout, transposed=False, bias=None, rowadd=None,
-                 residual=None, ld_res=0, preact=None, dact_u=None, ld_dact=0, act=ACT_NONE, alpha=1.0, drop_p=0.0, seed=0):
+                 residual=None, ld_res=0, preact=None, dact_u=None, ld_dact=0, act=ACT_NONE, alpha=1.0, drop_p=0.0, seed=0, flags=0):
     B, Hi, Wi, Ho, Wo, ks, stride, pad = geom
     d = ConvDesc()
     d.dtype = dtype_code(dtype)
     d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout = B, Hi, Wi, Cin, Ho, Wo, Cout
     d.ksize, d.stride, d.pad, d.transposed, d.act = ks, stride, pad, int(transposed), act
-    d.alpha, d.drop_p, d.drop_seed = float(alpha), float(drop_p), int(seed)
+    d.alpha, d.drop_p, d.drop_seed, d.flags = float(alpha), float(drop_p), int(seed), int(flags)
     d.ldx, d.ldy, d.ldw = ldx, ldy, ldw
     d.x, d.w, d.y = x.data_ptr(), w if isinstance(w, int) else w.data_ptr(), y.data_ptr()
     d.bias = bias.data_ptr() if bias is not None else None
@@ -486,7 +486,9 @@ class _FFNFn(torch.autograd.Function):
         hmid = torch.empty((M, Hd), dtype=dtype, device=x.device)
         y = torch.empty(x.shape, dtype=dtype, device=x.device)
         g1 = (M, 1, 1, 1, 1, 1, 1, 0)
-        _conv_launch(lib, dtype, xr, ldx, wf1, 0, hmid, Hd, g1, C, Hd, bias=b1, preact=u, act=ACT_GELU, drop_p=drop_p, seed=seed1)
+        # `u` receives gelu'(W1 x + b1) * mask1 / (1 - p), not the pre-activation: backward multiplies by it
+        _conv_launch(lib, dtype, xr, ldx, wf1, 0, hmid, Hd, g1, C, Hd, bias=b1, preact=u, act=ACT_GELU, drop_p=drop_p, seed=seed1,
+                     flags=_lib.CONV_SAVE_DACT if u is not None else 0)
         _conv_launch(lib, dtype, hmid, Hd, wf2, 0, y, C, g1, Hd, C, bias=b2, residual=xr, ld_res=ldx, alpha=alpha, drop_p=drop_p, seed=seed2)
         ctx.save_for_backward(xr, u, hmid, w1, w2)
         ctx.params = (w1, b1, w2, b2)
@@ -512,7 +514,7 @@ class _FFNFn(torch.autograd.Function):
                                    dtype_code(dtype), stream_ptr()), "psg_epilogue_bwd")
         # d/du of the first Linear's pre-activation: dgrad of Linear 2 with the backward-form epilogue
         gu = torch.empty((M, Hd), dtype=dtype, device=dy.device)
-        _conv_launch(lib, dtype, g2, C, wd2, 0, gu, Hd, geo, C, Hd, transposed=True, dact_u=u, ld_dact=Hd, act=ACT_GELU, drop_p=drop_p, seed=seed1)
+        _conv_launch(lib, dtype, g2, C, wd2, 0, gu, Hd, geo, C, Hd, transposed=True, dact_u=u, ld_dact=Hd, flags=_lib.CONV_DACT_MUL)
 
         def wgrad(xin, ldxin, g, ldg, wp, bp, cin, cout):
             wo, wacc, we = _param_out(wp)
