@@ -23,7 +23,7 @@ int oracle_noise_add_f32(const float* x0, const float* noise, const int64_t* t,
         const float a = tabA[t[b]], c = tabB[t[b]];
         for (int64_t i = 0; i < chw; ++i) {
             float x = x0[b * chw + i];
-            if (do_clamp) x = fminf(fmaxf(x, -3.0f), 3.0f);      /* torch.clamp(latent,-3,3) :363 */
+            if (do_clamp && x == x) x = fminf(fmaxf(x, -3.0f), 3.0f);   /* torch.clamp(latent,-3,3) :363 - NaN stays NaN */
             const float p = a * x;
             const float q = c * noise[b * chw + i];
             const float r = p + q;

@@ -26,6 +26,10 @@ static inline int grid_for(int64_t n, int block, int max_blocks = 2048) {
     return (int)g;
 }
 
+// torch.clamp(x, -3, 3) (improved_diffusion_trainer.py:363): NaN stays NaN (fminf / fmaxf alone would turn it into a bound
+// and hide a bad latent from the NaN checks that follow)
+__device__ __forceinline__ float clamp3(float x) { return x != x ? x : fminf(fmaxf(x, -3.0f), 3.0f); }
+
 // ---------------------------------------------------------------------------
 // add_noise: bit-exact (two rounded multiplies, one rounded add; no FMA contraction)
 // ---------------------------------------------------------------------------
@@ -41,7 +45,7 @@ __global__ void noise_add_kernel(const float* __restrict__ x0, const float* __re
         if (tb < 0 || tb >= num_t) { bad |= 2; tb = tb < 0 ? 0 : num_t - 1; }
         const float a = tabA[tb], c = tabB[tb];
         float x = x0[i];
-        if (do_clamp) x = fminf(fmaxf(x, -3.0f), 3.0f);
+        if (do_clamp) x = clamp3(x);
         const float r = __fadd_rn(__fmul_rn(a, x), __fmul_rn(c, noise[i]));
         out[i] = r;
         if (isnan(r) || isinf(r)) bad |= PSG_FLAG_FALLBACK;      // the reference then returns x0 + 0.1*noise (:61-63)
@@ -56,7 +60,7 @@ __global__ void noise_fallback_kernel(const float* __restrict__ x0, const float*
     int bad = 0;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float x = x0[i];
-        if (do_clamp) x = fminf(fmaxf(x, -3.0f), 3.0f);
+        if (do_clamp) x = clamp3(x);
         const float r = __fadd_rn(x, __fmul_rn(0.1f, noise[i]));
         out[i] = r;
         if (isnan(r) || isinf(r)) bad = PSG_FLAG_NOISY_BAD;     // the rescued batch is still non-finite: :376 skips it

@@ -1,5 +1,15 @@
 // GroupNorm (+ fused SiLU) forward / backward, channels-last [B, HW, C].  Roofline: HBM.
 //
+// FUSED (register-resident) path - every shape of the U-Net: one workgroup owns one (sample, channel slab) - a run of
+// whole groups whose width is a multiple of the 16-byte chunk - and keeps the slab's HW x slabC values IN REGISTERS
+// (<= 16 packed 16-byte chunks per lane), so the tensor is read from memory exactly once:
+//   forward : load -> channel sums -> group mean -> centred second pass over the registers (exact two-pass variance,
+//             no E[x^2]-E[x]^2 cancellation) -> normalise (+SiLU) -> store              = 1 read + 1 write
+//   backward: load x, dy -> per-channel (sum dz*xhat, sum dz) -> group sums -> dx (+ the bypass gradient) -> store;
+//             per-sample channel sums go to the workspace for dgamma / dbeta            = 2(+1) reads + 1 write
+// against 2 + 1 and 4 + 1 passes of the split kernels below (kept as the general fallback: shapes whose slab does not
+// fit the register budget).  Reductions are fixed-order LDS trees, as below: results are run-to-run identical.
+//
 // Every pass streams whole pixel rows with 16-byte vectors per lane (a thread owns one fixed
 // 16-byte channel chunk and walks pixels), so loads/stores are fully coalesced for every
 // channels-per-group value (10, 20, 40, 80: a chunk may straddle two groups - handled per
@@ -288,6 +298,306 @@ __global__ __launch_bounds__(1024) void gn_param_reduce_kernel(const float* __re
     }
 }
 
+
+// ---------------------------------------------------------------- fused, register-resident kernels
+struct GnF {
+    const void *x, *dy, *dres; void *y, *dx;
+    const float *gamma, *beta; float *mean, *rstd, *chan_ws;
+    int64_t ldx, ldy, lddy, lddres, lddx;
+    int B, HW, C, G, Cg, slabC, CCs, PP, nslab, SG;   // slabC channels = CCs chunks = SG groups per slab; PP pixel lanes
+    float eps; int silu;
+};
+
+// A chunk of N consecutive channels as it lies in memory (bf16 stays packed in registers).  The forward kernel moves
+// 16-byte chunks; the backward kernel, which holds TWO tensors plus twice the per-channel constants, moves 8-byte
+// chunks: the per-element state (constants, temporaries) halves while the slab bytes per lane stay the same.
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+template <typename T, int N> struct Chk;
+template <> struct Chk<float, 4> { typedef f32x4 type; };
+template <> struct Chk<float, 2> { typedef f32x2 type; };
+template <> struct Chk<bf16_t, 8> { typedef bf16x8 type; };
+template <> struct Chk<bf16_t, 4> { typedef bf16x4 type; };
+template <typename T, int N> __device__ __forceinline__ float chk_get(const typename Chk<T, N>::type& r, int e) { return (float)r[e]; }
+template <typename T, int N> __device__ __forceinline__ void chk_st(void* p, const float* v) {
+    typename Chk<T, N>::type t;
+#pragma unroll
+    for (int e = 0; e < N; ++e) t[e] = (T)v[e];
+    *reinterpret_cast<typename Chk<T, N>::type*>(p) = t;
+}
+
+// sums over the PP pixel lanes of sm[pl][ch] (ch < slabC), then over each group's channels: out[g] for g < SG.
+// `chan` (slabC floats) receives the per-channel totals.  Fixed order.  Ends with a barrier.
+__device__ __forceinline__ void gn_tree(const GnF& p, const float* part, float* chan, float* grp, int stride, int comp) {
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < p.slabC; ch += blockDim.x) {
+        float t = 0.f;
+        for (int l = 0; l < p.PP; ++l) t += part[((int64_t)l * p.slabC + ch) * stride + comp];
+        chan[ch] = t;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < p.SG) {
+        float t = 0.f;
+        for (int ch = threadIdx.x * p.Cg; ch < ((int)threadIdx.x + 1) * p.Cg; ++ch) t += chan[ch];
+        grp[threadIdx.x] = t;
+    }
+    __syncthreads();
+}
+
+// Workgroup ids go to the 8 XCDs round-robin; the slabs of ONE sample (consecutive logical ids) share 64-byte sectors
+// when a slab row is narrower than a sector pair, so each XCD gets a contiguous range of logical ids: the partner
+// slab's half of a sector is then an L2 hit instead of a second fetch through the fabric.
+__device__ __forceinline__ int gn_xcd_lid() {
+    const int nb = gridDim.x, bid = blockIdx.x;
+    const int q = nb >> 3, r = nb & 7, xcd = bid & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// The packed chunks are converted to fp32 again in every pass: without this fence hipcc keeps one fp32 copy of the whole
+// slab live across the passes (2x the registers of the packed form, which is what bounds the slab a workgroup can hold).
+template <typename Raw, int R>
+__device__ __forceinline__ void gn_fence(Raw (&raw)[R]) {
+#pragma unroll
+    for (int r = 0; r < R; ++r) asm volatile("" : "+v"(raw[r]));
+}
+
+template <typename T, int N, int R>
+__global__ __launch_bounds__(512, 4) void gn_fwd_fused_kernel(const GnF p) {
+    typedef typename Chk<T, N>::type Raw;
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // [PP][slabC] partials | [slabC] | [SG] | [SG]
+    float* chan = sm + (int64_t)p.PP * p.slabC;
+    float* gmean = chan + p.slabC;
+    float* gvar = gmean + p.SG;
+    const int lid = gn_xcd_lid();
+    const int b = lid / p.nslab, slab = lid - b * p.nslab;
+    const int c = threadIdx.x % p.CCs, pl = threadIdx.x / p.CCs;
+    const int ch0 = slab * p.slabC + c * N;
+    // Addresses = wave-uniform 64-bit base (sample, slab, chunk row r: scalar registers) + ONE 32-bit per-lane offset per
+    // tensor.  (Per-chunk 64-bit vector addresses - base + px*ld, or a bumped pointer, which hipcc unrolls back into
+    // R independent addresses - cost 2 x R registers per tensor: more than the packed slab itself.)
+    constexpr int ESZ = (int)sizeof(T);
+    const char* xs = reinterpret_cast<const char*>(p.x) + ((int64_t)b * p.HW * p.ldx + slab * p.slabC) * ESZ;
+    const uint32_t xo = (uint32_t)((pl * (int)p.ldx + c * N) * ESZ);
+    const uint32_t xstep = (uint32_t)(p.PP * (int)p.ldx * ESZ);      // (32-bit: a sample's slab spans far less than 4 GiB)
+    Raw raw[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (pl + r * p.PP < p.HW) raw[r] = *reinterpret_cast<const Raw*>(xs + (uint32_t)(xo + r * xstep));
+        else { Raw z = {}; raw[r] = z; }
+    }
+    // A chunk lies in at most two groups (Cg >= N, checked by the plan): group glo for elements e < eb, glo + 1 after.
+    // (Per-element group indices would cost a division and an LDS address register per element and per table.)
+    const int glo = (c * N) / p.Cg, eb = (glo + 1) * p.Cg - c * N;
+    const int ghi = min(glo + 1, p.SG - 1);
+    // ---- pass A: means
+    float s[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) s[e] = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int e = 0; e < N; ++e) s[e] += chk_get<T, N>(raw[r], e);   // (absent pixels hold zeros)
+    float* row = sm + (int64_t)pl * p.slabC + c * N;
+#pragma unroll
+    for (int e = 0; e < N; ++e) row[e] = s[e];
+    gn_tree(p, sm, chan, gmean, 1, 0);
+    gn_fence(raw);
+    const float inv_n = 1.0f / ((float)p.HW * (float)p.Cg);
+    float mu[N];
+    {
+        const float m_lo = gmean[glo] * inv_n, m_hi = gmean[ghi] * inv_n;
+#pragma unroll
+        for (int e = 0; e < N; ++e) mu[e] = e < eb ? m_lo : m_hi;
+    }
+    // ---- pass B: centred second moment, from the registers
+#pragma unroll
+    for (int e = 0; e < N; ++e) s[e] = 0.f;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float w = (pl + r * p.PP) < p.HW ? 1.f : 0.f;
+#pragma unroll
+        for (int e = 0; e < N; ++e) { const float d = chk_get<T, N>(raw[r], e) - mu[e]; s[e] += w * d * d; }
+    }
+#pragma unroll
+    for (int e = 0; e < N; ++e) row[e] = s[e];
+    gn_tree(p, sm, chan, gvar, 1, 0);
+    gn_fence(raw);
+    if ((int)threadIdx.x < p.SG) {
+        const int g = slab * p.SG + threadIdx.x;
+        p.mean[b * p.G + g] = gmean[threadIdx.x] * inv_n;
+        p.rstd[b * p.G + g] = 1.0f / sqrtf(gvar[threadIdx.x] * inv_n + p.eps);
+    }
+    // ---- normalise (+SiLU) and store
+    float sc[N], sh[N];
+    {
+        const float r_lo = 1.0f / sqrtf(gvar[glo] * inv_n + p.eps), r_hi = 1.0f / sqrtf(gvar[ghi] * inv_n + p.eps);
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            sc[e] = (e < eb ? r_lo : r_hi) * p.gamma[ch0 + e];
+            sh[e] = p.beta[ch0 + e] - mu[e] * sc[e];
+        }
+    }
+    char* ys = reinterpret_cast<char*>(p.y) + ((int64_t)b * p.HW * p.ldy + slab * p.slabC) * ESZ;
+    const uint32_t yo = (uint32_t)((pl * (int)p.ldy + c * N) * ESZ);
+    const uint32_t ystep = (uint32_t)(p.PP * (int)p.ldy * ESZ);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (pl + r * p.PP < p.HW) {
+            float v[N];
+#pragma unroll
+            for (int e = 0; e < N; ++e) { v[e] = chk_get<T, N>(raw[r], e) * sc[e] + sh[e]; if (p.silu) v[e] = silu_f(v[e]); }
+            chk_st<T, N>(ys + (uint32_t)(yo + r * ystep), v);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+template <typename T, int N, int R>
+__global__ __launch_bounds__(512, 4) void gn_bwd_fused_kernel(const GnF p) {
+    typedef typename Chk<T, N>::type Raw;
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // [PP][slabC][2] partials | [2][slabC] | 4 x [SG]
+    float* chan = sm + (int64_t)p.PP * p.slabC * 2;
+    float* g1 = chan + 2 * p.slabC;
+    float* g2 = g1 + p.SG;
+    float* gmu = g2 + p.SG;          // the slab's group statistics, staged once (per-element global addresses of mean /
+    float* grs = gmu + p.SG;         // rstd kept live across the passes cost 32 registers)
+    const int lid = gn_xcd_lid();
+    const int b = lid / p.nslab, slab = lid - b * p.nslab;
+    const int c = threadIdx.x % p.CCs, pl = threadIdx.x / p.CCs;
+    const int ch0 = slab * p.slabC + c * N;
+    // (uniform 64-bit bases + one 32-bit lane offset per tensor: see the forward kernel)
+    constexpr int ESZ = (int)sizeof(T);
+    const char* xs = reinterpret_cast<const char*>(p.x) + ((int64_t)b * p.HW * p.ldx + slab * p.slabC) * ESZ;
+    const char* gs = reinterpret_cast<const char*>(p.dy) + ((int64_t)b * p.HW * p.lddy + slab * p.slabC) * ESZ;
+    const uint32_t xo = (uint32_t)((pl * (int)p.ldx + c * N) * ESZ), go = (uint32_t)((pl * (int)p.lddy + c * N) * ESZ);
+    const uint32_t xstep = (uint32_t)(p.PP * (int)p.ldx * ESZ), gstep = (uint32_t)(p.PP * (int)p.lddy * ESZ);
+    Raw rx[R], rd[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (pl + r * p.PP < p.HW) {
+            rx[r] = *reinterpret_cast<const Raw*>(xs + (uint32_t)(xo + r * xstep));
+            rd[r] = *reinterpret_cast<const Raw*>(gs + (uint32_t)(go + r * gstep));
+        } else { Raw z = {}; rx[r] = z; rd[r] = z; }
+    }
+    if ((int)threadIdx.x < p.SG) {
+        gmu[threadIdx.x] = p.mean[b * p.G + slab * p.SG + threadIdx.x];
+        grs[threadIdx.x] = p.rstd[b * p.G + slab * p.SG + threadIdx.x];
+    }
+    __syncthreads();
+    const int glo = (c * N) / p.Cg, eb = (glo + 1) * p.Cg - c * N;      // (two groups per chunk at most: see the forward kernel)
+    const int ghi = min(glo + 1, p.SG - 1);
+    const float m_lo = gmu[glo], m_hi = gmu[ghi], r_lo = grs[glo], r_hi = grs[ghi];
+    float A[N], Bc[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        A[e] = (e < eb ? r_lo : r_hi) * p.gamma[ch0 + e];
+        Bc[e] = p.beta[ch0 + e] - (e < eb ? m_lo : m_hi) * A[e];
+    }
+    float a0[N], a1[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) { a0[e] = 0.f; a1[e] = 0.f; }
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+#pragma unroll
+        for (int e = 0; e < N; ++e) {
+            const float xv = chk_get<T, N>(rx[r], e);
+            float dz = chk_get<T, N>(rd[r], e);                  // (absent pixels hold dy = 0)
+            if (p.silu) dz *= silu_grad(xv * A[e] + Bc[e]);
+            a0[e] += dz * xv; a1[e] += dz;
+        }
+        __builtin_amdgcn_sched_barrier(0);      // one chunk's temporaries at a time (else hipcc interleaves all R: spills)
+    }
+    float* row = sm + ((int64_t)pl * p.slabC + c * N) * 2;
+#pragma unroll
+    for (int e = 0; e < N; ++e) { row[2 * e] = a0[e]; row[2 * e + 1] = a1[e]; }
+    // channel totals, per-sample (sum dz*xhat, sum dz) out for dgamma / dbeta, gamma-weighted group sums
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < p.slabC; ch += blockDim.x) {
+        float t0 = 0.f, t1 = 0.f;
+        for (int l = 0; l < p.PP; ++l) { t0 += sm[((int64_t)l * p.slabC + ch) * 2]; t1 += sm[((int64_t)l * p.slabC + ch) * 2 + 1]; }
+        const float m_ = gmu[ch / p.Cg], r_ = grs[ch / p.Cg];
+        const float dzh = r_ * t0 - m_ * r_ * t1;          // sum dz * xhat
+        float* o = p.chan_ws + ((int64_t)b * p.C + slab * p.slabC + ch) * 2;
+        o[0] = dzh; o[1] = t1;
+        const float gm = p.gamma[slab * p.slabC + ch];
+        chan[ch] = dzh * gm;                // sum(dxhat * xhat) contribution
+        chan[p.slabC + ch] = t1 * gm;       // sum(dxhat)
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < p.SG) {
+        float t0 = 0.f, t1 = 0.f;
+        for (int ch = threadIdx.x * p.Cg; ch < ((int)threadIdx.x + 1) * p.Cg; ++ch) { t0 += chan[ch]; t1 += chan[p.slabC + ch]; }
+        const float inv_n = 1.0f / ((float)p.HW * (float)p.Cg);
+        g2[threadIdx.x] = t0 * inv_n; g1[threadIdx.x] = t1 * inv_n;
+    }
+    __syncthreads();
+    gn_fence(rx);
+    gn_fence(rd);
+    float P[N], Q[N];
+    {
+        const float P_lo = r_lo * r_lo * g2[glo], P_hi = r_hi * r_hi * g2[ghi];
+        const float Q_lo = m_lo * P_lo - r_lo * g1[glo], Q_hi = m_hi * P_hi - r_hi * g1[ghi];
+#pragma unroll
+        for (int e = 0; e < N; ++e) { P[e] = e < eb ? P_lo : P_hi; Q[e] = e < eb ? Q_lo : Q_hi; }
+    }
+    char* os = reinterpret_cast<char*>(p.dx) + ((int64_t)b * p.HW * p.lddx + slab * p.slabC) * ESZ;
+    const char* rb = p.dres ? reinterpret_cast<const char*>(p.dres) + ((int64_t)b * p.HW * p.lddres + slab * p.slabC) * ESZ : nullptr;
+    const uint32_t oo = (uint32_t)((pl * (int)p.lddx + c * N) * ESZ), ro = (uint32_t)((pl * (int)p.lddres + c * N) * ESZ);
+    const uint32_t ostep = (uint32_t)(p.PP * (int)p.lddx * ESZ), rstep = (uint32_t)(p.PP * (int)p.lddres * ESZ);
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        if (pl + r * p.PP < p.HW) {
+            float v[N];
+            Raw res = {};
+            if (rb) res = *reinterpret_cast<const Raw*>(rb + (uint32_t)(ro + r * rstep));
+#pragma unroll
+            for (int e = 0; e < N; ++e) {
+                const float xv = chk_get<T, N>(rx[r], e);
+                float dz = chk_get<T, N>(rd[r], e);
+                if (p.silu) dz *= silu_grad(xv * A[e] + Bc[e]);
+                v[e] = A[e] * dz - xv * P[e] + Q[e];
+                if (rb) v[e] += chk_get<T, N>(res, e);
+            }
+            chk_st<T, N>(os + (uint32_t)(oo + r * ostep), v);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+static int gcd_i(int a, int b) { while (b) { const int t = a % b; a = b; b = t; } return a; }
+
+// Slab plan of the fused kernels: the widest run of whole groups (a multiple of the 16-byte chunk that divides C) whose
+// HW x slabC values fit rmax chunks per lane within max_threads lanes.  Returns R (4, 8 or 16), or 0 = use the split kernels.
+static int gn_fused_plan(GnF& p, int N, int max_threads, int rmax) {
+    static int off = -1;
+    if (off < 0) { const char* e = getenv("PSG_GN_FUSED"); off = (e && atoi(e) == 0) ? 1 : 0; }
+    if (off) return 0;
+    if (p.C % p.G || p.C % N) return 0;
+    p.Cg = p.C / p.G;
+    if (p.Cg < N) return 0;                                // (a chunk must not span more than two groups)
+    const int U = p.Cg / gcd_i(p.Cg, N) * N;             // lcm(Cg, N): smallest slab of whole groups and whole chunks
+    if (p.C % U) return 0;
+    const int units = p.C / U;
+    int best_k = 0;
+    for (int k = 1; k <= units; ++k) {
+        if (units % k) continue;
+        const int ccs = k * U / N;
+        const int pp_need = (p.HW + rmax - 1) / rmax;
+        if (ccs * pp_need > max_threads || k * U > 640) break;
+        best_k = k;
+    }
+    if (!best_k) return 0;
+    p.slabC = best_k * U; p.CCs = p.slabC / N; p.SG = p.slabC / p.Cg; p.nslab = p.C / p.slabC;
+    int pp = (p.HW + rmax - 1) / rmax;
+    const int pp_min = (256 + p.CCs - 1) / p.CCs;        // at least ~256 lanes per workgroup
+    if (pp < pp_min) pp = pp_min;
+    if (pp > p.HW) pp = p.HW;
+    if (p.CCs * pp > max_threads) pp = max_threads / p.CCs;
+    p.PP = pp;
+    const int r = (p.HW + pp - 1) / pp;
+    if (r > rmax) return 0;
+    return r <= 4 ? 4 : (r <= 8 ? 8 : 16);
+}
+
 static int gn_plan(GnP& p, int dtype) {
     const int N = dtype == PSG_BF16 ? 8 : 4;
     PSG_REQUIRE(p.B > 0 && p.HW > 0 && p.C > 0 && p.G > 0 && p.C % p.G == 0, PSG_ERR_SHAPE, "groupnorm: B=%d HW=%d C=%d G=%d", p.B, p.HW, p.C, p.G);
@@ -336,6 +646,22 @@ int psg_groupnorm_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, const fl
     const int threads = p.CC * p.PP, grid = B * p.NS;
     const size_t lds1 = (size_t)p.PP * C * 2 * sizeof(float), lds2 = (size_t)G * 2 * sizeof(float);
     ProfScope prof(PROF_GN, 2.0 * (double)B * HW * C * (double)(dtype == PSG_BF16 ? 2 : 4), s);
+    {
+        GnF f = {};
+        f.x = x; f.y = y; f.gamma = gamma; f.beta = beta; f.mean = mean; f.rstd = rstd; f.ldx = ldx; f.ldy = ldy;
+        f.B = B; f.HW = HW; f.C = C; f.G = G; f.eps = eps; f.silu = silu;
+        const int R = gn_fused_plan(f, dtype == PSG_BF16 ? 8 : 4, 512, 16);
+        const size_t lds = ((size_t)f.PP * f.slabC + f.slabC + 2 * f.SG) * sizeof(float);
+        if (R && lds <= 64 * 1024) {
+            const dim3 g(B * f.nslab), t(f.CCs * f.PP);
+#define PSG_GN_FWD(TT, NN, RR) hipLaunchKernelGGL((gn_fwd_fused_kernel<TT, NN, RR>), g, t, lds, s, f)
+            if (dtype == PSG_F32) { if (R == 4) PSG_GN_FWD(float, 4, 4); else if (R == 8) PSG_GN_FWD(float, 4, 8); else PSG_GN_FWD(float, 4, 16); }
+            else { if (R == 4) PSG_GN_FWD(bf16_t, 8, 4); else if (R == 8) PSG_GN_FWD(bf16_t, 8, 8); else PSG_GN_FWD(bf16_t, 8, 16); }
+#undef PSG_GN_FWD
+            PSG_LAUNCH_CHECK("groupnorm_fwd_fused");
+            return PSG_OK;
+        }
+    }
     if (dtype == PSG_F32) {
         hipLaunchKernelGGL(gn_stats_kernel<float>, dim3(grid), dim3(threads), lds1, s, p);
         hipLaunchKernelGGL(gn_apply_kernel<float>, dim3(grid), dim3(threads), lds2, s, p);
@@ -373,7 +699,26 @@ int psg_groupnorm_bwd_res(const void* dy, int64_t lddy, const void* x, int64_t l
     hipStream_t s = (hipStream_t)stream;
     const int threads = p.CC * p.PP, grid = B * p.NS;
     const size_t lds1 = (size_t)p.PP * C * 2 * sizeof(float), lds2 = ((size_t)C + G) * 2 * sizeof(float);
-    ProfScope prof(PROF_GN, 3.0 * (double)B * HW * C * (double)(dtype == PSG_BF16 ? 2 : 4), s);
+    ProfScope prof(PROF_GN, (dres ? 4.0 : 3.0) * (double)B * HW * C * (double)(dtype == PSG_BF16 ? 2 : 4), s);
+    {
+        GnF f = {};
+        f.x = x; f.dy = dy; f.dres = dres; f.dx = dx; f.gamma = gamma; f.beta = beta; f.mean = const_cast<float*>(mean);
+        f.rstd = const_cast<float*>(rstd); f.chan_ws = (float*)ws; f.ldx = ldx; f.lddy = lddy; f.lddres = lddres; f.lddx = lddx;
+        f.B = B; f.HW = HW; f.C = C; f.G = G; f.silu = silu;
+        const int R = gn_fused_plan(f, dtype == PSG_BF16 ? 4 : 2, 512, 8);           // 8-byte chunks, <= 8 per lane and tensor
+        const size_t lds = ((size_t)f.PP * f.slabC * 2 + 2 * f.slabC + 4 * f.SG) * sizeof(float);
+        if (R && lds <= 64 * 1024) {
+            const dim3 g(B * f.nslab), t(f.CCs * f.PP);
+#define PSG_GN_BWD(TT, NN, RR) hipLaunchKernelGGL((gn_bwd_fused_kernel<TT, NN, RR>), g, t, lds, s, f)
+            if (dtype == PSG_F32) { if (R == 4) PSG_GN_BWD(float, 2, 4); else PSG_GN_BWD(float, 2, 8); }
+            else { if (R == 4) PSG_GN_BWD(bf16_t, 4, 4); else PSG_GN_BWD(bf16_t, 4, 8); }
+#undef PSG_GN_BWD
+            PSG_LAUNCH_CHECK("groupnorm_bwd_fused");
+            hipLaunchKernelGGL(gn_param_reduce_kernel, dim3((C + 31) / 32), dim3(1024), 0, s, (const float*)ws, dgamma, dbeta, B, C, accumulate);
+            PSG_LAUNCH_CHECK("groupnorm_param_reduce");
+            return PSG_OK;
+        }
+    }
     if (dtype == PSG_F32) {
         hipLaunchKernelGGL(gn_bwd_reduce_kernel<float>, dim3(grid), dim3(threads), lds1, s, p);
         hipLaunchKernelGGL(gn_bwd_apply_kernel<float>, dim3(grid), dim3(threads), lds2, s, p);

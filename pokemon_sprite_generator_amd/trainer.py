@@ -207,7 +207,8 @@ class SamplerRun:
         stepper.unet.eval()
         dev = stepper.device
         self.rnd = noise_fn if noise_fn is not None else (lambda i, shape: torch.randn(shape, device=dev))
-        self.x = self.rnd(-1, (num_samples, latent_dim, hw, hw)).to(dev).float().contiguous()
+        # (own copy: the chain updates x in place and must not write into the caller's x_T)
+        self.x = self.rnd(-1, (num_samples, latent_dim, hw, hw)).to(device=dev, dtype=torch.float32).contiguous().clone()
         sch = stepper.noise_scheduler.to(dev)
         self.c1, self.c2, self.sg = sch.step_tables(dev)
         T = sch.num_timesteps

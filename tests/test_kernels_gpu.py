@@ -98,14 +98,25 @@ def test_c_oracle_agrees(psg):
     subprocess.check_call(["make", "-C", os.path.join(root, "oracle")], stdout=subprocess.DEVNULL)
     lib = C.CDLL(os.path.join(root, "oracle", "libpsg_oracle.so"))
     x0, nz = h((4, 8, 27, 27), "c.x0", 3.5), h((4, 8, 27, 27), "c.nz", 1.0)
+    x0[3, 0, 0, :3] = torch.tensor([float("nan"), float("inf"), -float("inf")])      # clamp keeps NaN, bounds the infinities
     t = torch.tensor([0, 500, 999, 37], dtype=torch.int64)
     tb = O.cosine_clipped_tables()
     out = torch.empty_like(x0)
     f32p = lambda a: a.numpy().ctypes.data_as(C.c_void_p)
     lib.oracle_noise_add_f32(f32p(x0), f32p(nz), t.numpy().ctypes.data_as(C.c_void_p), f32p(tb["sqrt_alphas_cumprod"]),
                              f32p(tb["sqrt_one_minus_alphas_cumprod"]), f32p(out), None, C.c_int64(4), C.c_int64(8 * 27 * 27), 1)
-    got = psg.NoiseScheduler().add_noise(x0.to(DEV), nz.to(DEV), t.to(DEV), clamp=True).cpu()
-    assert torch.equal(got, out)
+    sch = psg.NoiseScheduler()
+    flag = torch.zeros(1, dtype=torch.int32, device=DEV)
+    from pokemon_sprite_generator_amd import _lib
+    got = torch.empty_like(x0, device=DEV)
+    _lib.check(_lib.init(0).psg_noise_add_f32(_lib.ptr(x0.to(DEV)), _lib.ptr(nz.to(DEV)), _lib.ptr(t.to(DEV)),
+                                              _lib.ptr(sch.to(DEV).sqrt_alphas_cumprod), _lib.ptr(sch.sqrt_one_minus_alphas_cumprod),
+                                              _lib.ptr(got), _lib.ptr(flag), 4, 8 * 27 * 27, 1000, 1, _lib.stream_ptr()), "noise_add")
+    got = got.cpu()
+    ref = torch.clamp(x0, -3.0, 3.0)                                                  # torch's own clamp semantics
+    assert torch.isnan(out[3, 0, 0, 0]) and torch.isnan(got[3, 0, 0, 0]) and torch.isnan(ref[3, 0, 0, 0])
+    assert torch.equal(torch.nan_to_num(got, nan=7.0), torch.nan_to_num(out, nan=7.0))
+    assert int(flag.item()) == 16                                                     # the NaN asks for the fallback
 
 
 # ---------------------------------------------------------------- a-8 SmoothL1 / a-9 ddpm update
