@@ -325,22 +325,37 @@ template <typename T, int N> __device__ __forceinline__ void chk_st(void* p, con
     *reinterpret_cast<typename Chk<T, N>::type*>(p) = t;
 }
 
-// sums over the PP pixel lanes of sm[pl][ch] (ch < slabC), then over each group's channels: out[g] for g < SG.
-// `chan` (slabC floats) receives the per-channel totals.  Fixed order.  Ends with a barrier.
-__device__ __forceinline__ void gn_tree(const GnF& p, const float* part, float* chan, float* grp, int stride, int comp) {
+// sums over the PP pixel lanes of part[pl][ch][stride] (component comp), then over each group's channels: grp[g], g < SG.
+// Two levels so that the whole workgroup works (nseg = blockDim / slabC segments of the pixel lanes in parallel) instead
+// of slabC lanes walking PP dependent LDS reads each: the reduction phases are dead time for the memory pipe.
+// `seg` (nseg * slabC floats) and `chan` (slabC floats) are scratch.  Fixed order.  Ends with a barrier.
+__device__ __forceinline__ void gn_tree(const GnF& p, const float* part, float* seg, float* chan, float* grp, int stride, int comp) {
+    const int nseg = max(1, min((int)blockDim.x / p.slabC, p.PP));
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < nseg * p.slabC; idx += blockDim.x) {      // (one trip unless slabC > blockDim)
+        const int ch = idx % p.slabC, sg = idx / p.slabC;
+        float t0 = 0.f, t1 = 0.f;
+        int l = sg;
+        for (; l + nseg < p.PP; l += 2 * nseg) {
+            t0 += part[((int64_t)l * p.slabC + ch) * stride + comp];
+            t1 += part[((int64_t)(l + nseg) * p.slabC + ch) * stride + comp];
+        }
+        if (l < p.PP) t0 += part[((int64_t)l * p.slabC + ch) * stride + comp];
+        seg[sg * p.slabC + ch] = t0 + t1;
+    }
     __syncthreads();
     for (int ch = threadIdx.x; ch < p.slabC; ch += blockDim.x) {
         float t = 0.f;
-        for (int l = 0; l < p.PP; ++l) t += part[((int64_t)l * p.slabC + ch) * stride + comp];
+        for (int sg = 0; sg < nseg; ++sg) t += seg[sg * p.slabC + ch];
         chan[ch] = t;
     }
     __syncthreads();
-    if ((int)threadIdx.x < p.SG) {
+    if (grp && (int)threadIdx.x < p.SG) {
         float t = 0.f;
         for (int ch = threadIdx.x * p.Cg; ch < ((int)threadIdx.x + 1) * p.Cg; ++ch) t += chan[ch];
         grp[threadIdx.x] = t;
     }
-    __syncthreads();
+    if (grp) __syncthreads();
 }
 
 // Workgroup ids go to the 8 XCDs round-robin; the slabs of ONE sample (consecutive logical ids) share 64-byte sectors
@@ -363,8 +378,9 @@ __device__ __forceinline__ void gn_fence(Raw (&raw)[R]) {
 template <typename T, int N, int R>
 __global__ __launch_bounds__(512, 4) void gn_fwd_fused_kernel(const GnF p) {
     typedef typename Chk<T, N>::type Raw;
-    extern __shared__ __attribute__((aligned(16))) float sm[];      // [PP][slabC] partials | [slabC] | [SG] | [SG]
-    float* chan = sm + (int64_t)p.PP * p.slabC;
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // [PP][slabC] partials | [nseg][slabC] | [slabC] | [SG] | [SG]
+    float* segb = sm + (int64_t)p.PP * p.slabC;
+    float* chan = segb + max((int)blockDim.x, p.slabC);
     float* gmean = chan + p.slabC;
     float* gvar = gmean + p.SG;
     const int lid = gn_xcd_lid();
@@ -399,7 +415,7 @@ __global__ __launch_bounds__(512, 4) void gn_fwd_fused_kernel(const GnF p) {
     float* row = sm + (int64_t)pl * p.slabC + c * N;
 #pragma unroll
     for (int e = 0; e < N; ++e) row[e] = s[e];
-    gn_tree(p, sm, chan, gmean, 1, 0);
+    gn_tree(p, sm, segb, chan, gmean, 1, 0);
     gn_fence(raw);
     const float inv_n = 1.0f / ((float)p.HW * (float)p.Cg);
     float mu[N];
@@ -419,7 +435,7 @@ __global__ __launch_bounds__(512, 4) void gn_fwd_fused_kernel(const GnF p) {
     }
 #pragma unroll
     for (int e = 0; e < N; ++e) row[e] = s[e];
-    gn_tree(p, sm, chan, gvar, 1, 0);
+    gn_tree(p, sm, segb, chan, gvar, 1, 0);
     gn_fence(raw);
     if ((int)threadIdx.x < p.SG) {
         const int g = slab * p.SG + threadIdx.x;
@@ -454,9 +470,10 @@ __global__ __launch_bounds__(512, 4) void gn_fwd_fused_kernel(const GnF p) {
 template <typename T, int N, int R>
 __global__ __launch_bounds__(512, 4) void gn_bwd_fused_kernel(const GnF p) {
     typedef typename Chk<T, N>::type Raw;
-    extern __shared__ __attribute__((aligned(16))) float sm[];      // [PP][slabC][2] partials | [2][slabC] | 4 x [SG]
-    float* chan = sm + (int64_t)p.PP * p.slabC * 2;
-    float* g1 = chan + 2 * p.slabC;
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // [PP][slabC][2] partials | [nseg][slabC] | [4][slabC] | 4 x [SG]
+    float* segb = sm + (int64_t)p.PP * p.slabC * 2;
+    float* chan = segb + max((int)blockDim.x, p.slabC);              // [0],[1]: gamma-weighted; [2],[3]: raw channel totals
+    float* g1 = chan + 4 * p.slabC;
     float* g2 = g1 + p.SG;
     float* gmu = g2 + p.SG;          // the slab's group statistics, staged once (per-element global addresses of mean /
     float* grs = gmu + p.SG;         // rstd kept live across the passes cost 32 registers)
@@ -510,10 +527,10 @@ __global__ __launch_bounds__(512, 4) void gn_bwd_fused_kernel(const GnF p) {
 #pragma unroll
     for (int e = 0; e < N; ++e) { row[2 * e] = a0[e]; row[2 * e + 1] = a1[e]; }
     // channel totals, per-sample (sum dz*xhat, sum dz) out for dgamma / dbeta, gamma-weighted group sums
-    __syncthreads();
+    gn_tree(p, sm, segb, chan + 2 * p.slabC, nullptr, 2, 0);
+    gn_tree(p, sm, segb, chan + 3 * p.slabC, nullptr, 2, 1);
     for (int ch = threadIdx.x; ch < p.slabC; ch += blockDim.x) {
-        float t0 = 0.f, t1 = 0.f;
-        for (int l = 0; l < p.PP; ++l) { t0 += sm[((int64_t)l * p.slabC + ch) * 2]; t1 += sm[((int64_t)l * p.slabC + ch) * 2 + 1]; }
+        const float t0 = chan[2 * p.slabC + ch], t1 = chan[3 * p.slabC + ch];
         const float m_ = gmu[ch / p.Cg], r_ = grs[ch / p.Cg];
         const float dzh = r_ * t0 - m_ * r_ * t1;          // sum dz * xhat
         float* o = p.chan_ws + ((int64_t)b * p.C + slab * p.slabC + ch) * 2;
@@ -571,6 +588,7 @@ static int gn_fused_plan(GnF& p, int N, int max_threads, int rmax) {
     static int off = -1;
     if (off < 0) { const char* e = getenv("PSG_GN_FUSED"); off = (e && atoi(e) == 0) ? 1 : 0; }
     if (off) return 0;
+    { static int mt = -1; if (mt < 0) { const char* e = getenv("PSG_GN_MAXT"); mt = e ? atoi(e) : 0; } if (mt >= 64 && mt < max_threads) max_threads = mt; }
     if (p.C % p.G || p.C % N) return 0;
     p.Cg = p.C / p.G;
     if (p.Cg < N) return 0;                                // (a chunk must not span more than two groups)
@@ -650,8 +668,11 @@ int psg_groupnorm_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, const fl
         GnF f = {};
         f.x = x; f.y = y; f.gamma = gamma; f.beta = beta; f.mean = mean; f.rstd = rstd; f.ldx = ldx; f.ldy = ldy;
         f.B = B; f.HW = HW; f.C = C; f.G = G; f.eps = eps; f.silu = silu;
-        const int R = gn_fused_plan(f, dtype == PSG_BF16 ? 8 : 4, 512, 16);
-        const size_t lds = ((size_t)f.PP * f.slabC + f.slabC + 2 * f.SG) * sizeof(float);
+        // 256-lane workgroups first: four or more of them share a CU and their load / reduce / store phases interleave
+        // (measured: -9 % GroupNorm time against 512 lanes); 512 lanes where a 256-lane slab cannot hold whole groups
+        int R = gn_fused_plan(f, dtype == PSG_BF16 ? 8 : 4, 256, 16);
+        if (!R) R = gn_fused_plan(f, dtype == PSG_BF16 ? 8 : 4, 512, 16);
+        const size_t lds = ((size_t)f.PP * f.slabC + (f.CCs * f.PP > f.slabC ? f.CCs * f.PP : f.slabC) + f.slabC + 2 * f.SG) * sizeof(float);
         if (R && lds <= 64 * 1024) {
             const dim3 g(B * f.nslab), t(f.CCs * f.PP);
 #define PSG_GN_FWD(TT, NN, RR) hipLaunchKernelGGL((gn_fwd_fused_kernel<TT, NN, RR>), g, t, lds, s, f)
@@ -705,8 +726,9 @@ int psg_groupnorm_bwd_res(const void* dy, int64_t lddy, const void* x, int64_t l
         f.x = x; f.dy = dy; f.dres = dres; f.dx = dx; f.gamma = gamma; f.beta = beta; f.mean = const_cast<float*>(mean);
         f.rstd = const_cast<float*>(rstd); f.chan_ws = (float*)ws; f.ldx = ldx; f.lddy = lddy; f.lddres = lddres; f.lddx = lddx;
         f.B = B; f.HW = HW; f.C = C; f.G = G; f.silu = silu;
-        const int R = gn_fused_plan(f, dtype == PSG_BF16 ? 4 : 2, 512, 8);           // 8-byte chunks, <= 8 per lane and tensor
-        const size_t lds = ((size_t)f.PP * f.slabC * 2 + 2 * f.slabC + 4 * f.SG) * sizeof(float);
+        int R = gn_fused_plan(f, dtype == PSG_BF16 ? 4 : 2, 256, 8);                 // 8-byte chunks, <= 8 per lane and tensor
+        if (!R) R = gn_fused_plan(f, dtype == PSG_BF16 ? 4 : 2, 512, 8);
+        const size_t lds = ((size_t)f.PP * f.slabC * 2 + (f.CCs * f.PP > f.slabC ? f.CCs * f.PP : f.slabC) + 4 * f.slabC + 4 * f.SG) * sizeof(float);
         if (R && lds <= 64 * 1024) {
             const dim3 g(B * f.nslab), t(f.CCs * f.PP);
 #define PSG_GN_BWD(TT, NN, RR) hipLaunchKernelGGL((gn_bwd_fused_kernel<TT, NN, RR>), g, t, lds, s, f)

@@ -109,9 +109,11 @@ def test_c_oracle_agrees(psg):
     flag = torch.zeros(1, dtype=torch.int32, device=DEV)
     from pokemon_sprite_generator_amd import _lib
     got = torch.empty_like(x0, device=DEV)
-    _lib.check(_lib.init(0).psg_noise_add_f32(_lib.ptr(x0.to(DEV)), _lib.ptr(nz.to(DEV)), _lib.ptr(t.to(DEV)),
+    xd, nd, td = x0.to(DEV), nz.to(DEV), t.to(DEV)              # (kept alive: raw pointers are handed to the C ABI)
+    _lib.check(_lib.init(0).psg_noise_add_f32(_lib.ptr(xd), _lib.ptr(nd), _lib.ptr(td),
                                               _lib.ptr(sch.to(DEV).sqrt_alphas_cumprod), _lib.ptr(sch.sqrt_one_minus_alphas_cumprod),
                                               _lib.ptr(got), _lib.ptr(flag), 4, 8 * 27 * 27, 1000, 1, _lib.stream_ptr()), "noise_add")
+    torch.cuda.synchronize()
     got = got.cpu()
     ref = torch.clamp(x0, -3.0, 3.0)                                                  # torch's own clamp semantics
     assert torch.isnan(out[3, 0, 0, 0]) and torch.isnan(got[3, 0, 0, 0]) and torch.isnan(ref[3, 0, 0, 0])
