@@ -18,6 +18,7 @@
 // Workgroup ids are remapped XCD-aware (each XCD's L2 sees a contiguous range of
 // tiles) and rasterised in groups of 8 M-tiles sharing weight panels.
 #include "psg_common.h"
+#include <type_traits>
 
 namespace psg {
 
@@ -31,6 +32,7 @@ struct ConvP {
     int mtiles, ntiles;
     int act; float alpha;
     int flags;                     // PSG_CONV_SAVE_DACT / PSG_CONV_DACT_MUL
+    int epi_lds;                   // bf16: stage the output tile through LDS and store whole 16-byte row chunks
     uint32_t drop_thresh; float drop_scale; uint64_t drop_seed;
     uint32_t x_bytes, w_bytes;     // extents for the bounds-checked buffer loads
     // MODE 3 (one parity class of a stride-2 data gradient): result pixels (sub_h0 + 2i, sub_w0 + 2j), i < sub_nH,
@@ -83,17 +85,17 @@ __device__ __forceinline__ void conv_out_row(const ConvP& p, int mt, int& m, int
 // issued after a store cannot complete before that store has - with the loads inside this function every channel
 // group waited a full store round trip (16 per lane), which made every epilogue with a bias 1.4x slower than one
 // without (fwd vs dgrad of the same GEMM).
+// value(s) of the fused epilogue for 4 consecutive channels: `v` becomes the output value; returns in `pre` what the
+// `preact` buffer receives (the pre-activation u, or with PSG_CONV_SAVE_DACT the epilogue's derivative)
 template <typename T>
-__device__ __forceinline__ void conv_emit(const ConvP& p, int m, int n, f32x4 v, f32x4 bias4, f32x4 ra4, f32x4 aux4) {
+__device__ __forceinline__ void conv_value(const ConvP& p, int m, int n, f32x4& v, f32x4& pre, f32x4 bias4, f32x4 ra4, f32x4 aux4) {
     // aux4: the residual, or (backward form, dact_u set - the two are mutually exclusive) the saved pre-activation u /
     // the saved epilogue derivative
     constexpr bool FAST = sizeof(T) == 2;                  // bf16 compute: bf16-grade GELU (exact fp32 path keeps erff)
-    T* yg = reinterpret_cast<T*>(p.y);
-    T* preg = reinterpret_cast<T*>(p.preact);
     v += bias4 + ra4;
     const bool save_d = (p.flags & PSG_CONV_SAVE_DACT) != 0;
     f32x4 d = {1.f, 1.f, 1.f, 1.f};                        // d(epilogue value)/d(accumulator), apart from alpha
-    if (preg && !save_d) store4<T>(preg + (int64_t)m * p.ldpre + n, v);
+    pre = v;
     if (p.dact_u) {
         if (p.flags & PSG_CONV_DACT_MUL) v *= aux4;       // backward form, derivative saved by the forward launch
         else {
@@ -117,10 +119,30 @@ __device__ __forceinline__ void conv_emit(const ConvP& p, int m, int n, f32x4 v,
             d[e] = keep ? d[e] * p.drop_scale : 0.f;
         }
     }
-    if (preg && save_d) store4<T>(preg + (int64_t)m * p.ldpre + n, d);
+    if (save_d) pre = d;
     v *= p.alpha;
     if (!p.dact_u) v += aux4;
+}
+
+template <typename T>
+__device__ __forceinline__ void conv_emit(const ConvP& p, int m, int n, f32x4 v, f32x4 bias4, f32x4 ra4, f32x4 aux4) {
+    T* yg = reinterpret_cast<T*>(p.y);
+    T* preg = reinterpret_cast<T*>(p.preact);
+    f32x4 pre;
+    conv_value<T>(p, m, n, v, pre, bias4, ra4, aux4);
+    if (preg) store4<T>(preg + (int64_t)m * p.ldpre + n, pre);
     store4<T>(yg + (int64_t)m * p.ldy + n, v);
+}
+
+// y row of tile pixel mt (no sample index): the coalesced store pass of the LDS-staged epilogue
+template <int MODE>
+__device__ __forceinline__ int conv_out_m(const ConvP& p, int mt) {
+    if (MODE == 3) {
+        const int hw = p.sub_nH * p.sub_nW;
+        const int b = mt / hw, rm = mt - b * hw, i = rm / p.sub_nW, jj = rm - i * p.sub_nW;
+        return (b * p.Ho + p.sub_h0 + 2 * i) * p.Wo + p.sub_w0 + 2 * jj;
+    }
+    return mt;
 }
 
 // MODE 0: forward gather, K step inside one tap (Cin % K-step == 0)   [every 3x3 / 1x1 layer of the U-Net body]
@@ -356,6 +378,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
     int rows[FT16 ? NB : 1], smp[FT16 ? NB : 1];
     f32x4 bias4[FT16 ? NA : 1];
     bf16x4 res_raw[FT16 ? NA : 1][FT16 ? NB : 1];
+    // LDS-staged epilogue: the residual / saved derivative is fetched ROW-major instead (16 bytes per lane, whole 128-byte
+    // lines per instruction) and turned into the accumulator layout through the wave's LDS region - exact, it is bf16
+    constexpr int E_CPRW = FT16 ? WN / 8 : 1, E_NCH = FT16 ? WM * E_CPRW : 1, E_NIT = (E_NCH + 63) / 64;
+    uint4 res_row[FT16 ? E_NIT : 1];
     if constexpr (FT16) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -367,12 +393,25 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
             const int mt_ = m0 + wm * WM + j * 16 + l16;
             rows[j] = -1; smp[j] = 0;
             if (mt_ < p.M) conv_out_row<MODE>(p, mt_, rows[j], smp[j]);
-            if (resg) {
+            if (resg && !p.epi_lds) {
 #pragma unroll
                 for (int i = 0; i < NA; ++i) {
                     const int n = n0 + wn * WN + i * 16 + 4 * kq;
                     if (rows[j] >= 0 && n < p.N) res_raw[i][j] = *reinterpret_cast<const bf16x4*>(resg + (int64_t)rows[j] * ldaux + n);
                 }
+            }
+        }
+    }
+    if constexpr (FT16) {
+        if (resg && p.epi_lds) {
+#pragma unroll
+            for (int it = 0; it < E_NIT; ++it) {
+                const int idx = it * 64 + lane;
+                const int row = idx / E_CPRW, chk = idx - row * E_CPRW;
+                const int mt_ = m0 + wm * WM + row, n = n0 + wn * WN + chk * 8;
+                const uint4 z4 = {0u, 0u, 0u, 0u};
+                res_row[it] = (idx < E_NCH && mt_ < p.M && n < p.N)
+                                  ? *reinterpret_cast<const uint4*>(resg + (int64_t)conv_out_m<MODE>(p, mt_) * ldaux + n) : z4;
             }
         }
     }
@@ -389,6 +428,72 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
 
     // ---- fused epilogue: phase 1 loads every bias / residual operand of the tile, phase 2 computes and stores ----
     if constexpr (FT16) {
+        if (p.epi_lds) {
+            // LDS-staged stores.  In the accumulator layout a lane owns 4 channels of one pixel, so a store instruction
+            // writes 64 x 8 bytes in 32-byte pieces of 16 different rows: the store pipe, not the bandwidth, bounds the
+            // epilogue (and the epilogue, not the K loop, bounds every short-K layer).  Each wave instead writes its
+            // WM x WN sub-tile to its own LDS region (bf16, padded rows: conflict-free ds_write_b64) and reads it back
+            // row-major, 16 bytes per lane: a store instruction then writes whole 128-byte lines, half as many of them.
+            // Values are final (bias, activation, dropout, gate, residual all applied in fp32 BEFORE the staging: one
+            // rounding to bf16, bit-identical to the direct form).  `preact` takes the same route in a first pass.
+            constexpr int CPRW = WN / 8;                       // 16-byte chunks per sub-tile row
+            constexpr int PITCH = WN * 2 + 16;                 // bytes; (PITCH/4) mod 64 = 36 / 20 / 44: distinct banks for 16 rows
+            constexpr int NCH = WM * CPRW;                     // chunks per sub-tile
+            constexpr int NIT = (NCH + 63) / 64;
+            char* reg = smem + wave * (WM * PITCH);
+            auto stage_and_flush = [&](auto pass_c) {
+                constexpr int PASS = decltype(pass_c)::value;      // 0: the `preact` tensor, 1: y
+                if (resg) {                                        // residual rows -> LDS (read back per accumulator cell below)
+#pragma unroll
+                    for (int it = 0; it < NIT; ++it) {
+                        const int idx = it * 64 + lane;
+                        const int row = idx / CPRW, chk = idx - row * CPRW;
+                        if (idx < NCH) *reinterpret_cast<uint4*>(reg + row * PITCH + chk * 16) = res_row[it];
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    f32x4 ra4[NA];
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) {
+                        const int n = n0 + wn * WN + i * 16 + 4 * kq;
+                        ra4[i] = (rag && rows[j] >= 0 && n < p.N) ? load4<T>(rag + (int64_t)smp[j] * p.ldra + n) : zero4;
+                    }
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) {
+                        const int n = n0 + wn * WN + i * 16 + 4 * kq;
+                        f32x4 v = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                        f32x4 r4 = zero4, pre;
+                        char* cell = reg + (j * 16 + l16) * PITCH + (i * 16 + 4 * kq) * 2;     // this lane's 4 channels of pixel j*16+l16
+                        if (resg) {
+                            const bf16x4 rr = *reinterpret_cast<const bf16x4*>(cell);
+                            r4[0] = (float)rr[0]; r4[1] = (float)rr[1]; r4[2] = (float)rr[2]; r4[3] = (float)rr[3];
+                        }
+                        conv_value<T>(p, rows[j], n, v, pre, bias4[i], ra4[i], r4);
+                        const f32x4 o = PASS == 0 ? pre : v;
+                        bf16x4 ob = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
+                        *reinterpret_cast<bf16x4*>(cell) = ob;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);          // one pixel row of tiles at a time (register pressure)
+                }
+                T* dst = reinterpret_cast<T*>(PASS == 0 ? p.preact : p.y);
+                const int64_t ldd = PASS == 0 ? p.ldpre : p.ldy;
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int idx = it * 64 + lane;
+                    const int row = idx / CPRW, chk = idx - row * CPRW;
+                    const int mt_ = m0 + wm * WM + row, n = n0 + wn * WN + chk * 8;
+                    if (idx < NCH && mt_ < p.M && n < p.N) {
+                        const uint4 val = *reinterpret_cast<const uint4*>(reg + row * PITCH + chk * 16);
+                        *reinterpret_cast<uint4*>(dst + (int64_t)conv_out_m<MODE>(p, mt_) * ldd + n) = val;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            };
+            if (p.preact) stage_and_flush(std::integral_constant<int, 0>{});
+            stage_and_flush(std::integral_constant<int, 1>{});
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             if (rows[j] < 0) continue;
@@ -448,8 +553,12 @@ static int launch_conv(const ConvP& p, hipStream_t stream) {
     const int grid = q.mtiles * q.ntiles;
     ProfScope prof(p.transposed ? PROF_CONV_DGRAD : PROF_CONV_FWD, 2.0 * (double)p.M * (double)p.N * (double)p.taps * (double)p.Cin, stream);
     const int mode = p.ntap > 0 ? 3 : (!p.fast ? 2 : (!p.transposed ? 0 : (p.stride == 1 ? 1 : 2)));
-    if (mode == 3) hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 3>), dim3(grid), dim3(256), lds, stream, q);
-    else if (mode == 0) hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 0>), dim3(grid), dim3(256), lds, stream, q);
+    if (mode == 3) {
+        // (the 160-wide tiles are not built for the parity-class mode: its tap tables push the kernel past the scalar
+        //  register file - one layer, the first downsample's data gradient, runs 128x128 instead)
+        if constexpr (BN != 160) hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 3>), dim3(grid), dim3(256), lds, stream, q);
+        else return set_error(PSG_ERR_ARG, "conv_gemm: no 160-wide parity-class kernel");
+    } else if (mode == 0) hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 0>), dim3(grid), dim3(256), lds, stream, q);
     else if (mode == 1) hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 1>), dim3(grid), dim3(256), lds, stream, q);
     else hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 2>), dim3(grid), dim3(256), lds, stream, q);
     hipError_t e = hipGetLastError();
@@ -463,7 +572,8 @@ static int set_conv_attrs() {
     PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    if constexpr (BN != 160)
+        PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     return PSG_OK;
 }
 
@@ -477,7 +587,7 @@ static int choose_and_launch(const ConvP& p, int dtype, hipStream_t s) {
         const int cand[5][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 160}, {64, 160}};
         double eff[5] = {1.0, 0.78, 0.55, 1.0, 0.70};      // measured relative MFMA efficiency of the tile shapes
         if (p.KT <= 10) eff[1] = 1.1;                      // K <= 640: 3 resident 128x64 workgroups hide the short K loop's ends
-        if (dtype != PSG_BF16) eff[3] = eff[4] = 0.0;      // 160 = 2 x 5 x 16: only the 16x16x32 bf16 tiles divide it
+        if (dtype != PSG_BF16 || p.ntap > 0) eff[3] = eff[4] = 0.0;   // 160 = 2 x 5 x 16: only the 16x16x32 bf16 tiles divide it
         const double slots = 512.0;                        // resident workgroups on the chip (2 per CU)
         double best = -1.0;
         for (int c = 0; c < 5; ++c) {
@@ -568,6 +678,13 @@ int psg_conv_fwd(const psg_conv_desc* d, psg_stream_t stream) {
     p.M = (int)M; p.taps = taps; p.cpt = d->Cin / CH; p.Kpad = (int)Kpad; p.KT = (int)(Kpad / (8 * CH));
     p.fast = (p.cpt % 8 == 0) ? 1 : 0; p.tpt = p.fast ? p.cpt / 8 : 1;
     p.act = d->act; p.alpha = d->alpha; p.flags = d->flags;
+    {
+        // coalesced (LDS-staged) stores need 16-byte row chunks: bf16, channel counts and row strides multiples of 8
+        static int off = -1;
+        if (off < 0) { const char* e = getenv("PSG_EPI_LDS"); off = (e && atoi(e) == 0) ? 1 : 0; }
+        p.epi_lds = (!off && d->dtype == PSG_BF16 && d->Cout % 8 == 0 && d->ldy % 8 == 0 && (!d->preact || d->ld_preact % 8 == 0) &&
+                     (!d->residual || d->ld_residual % 8 == 0) && (!d->dact_u || d->ld_dact % 8 == 0)) ? 1 : 0;
+    }
     p.drop_thresh = d->drop_p > 0.f ? drop_thresh(d->drop_p) : 0u;
     p.drop_scale = d->drop_p > 0.f ? 1.0f / (1.0f - d->drop_p) : 1.0f;
     p.drop_seed = d->drop_seed;
