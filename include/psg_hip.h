@@ -92,6 +92,19 @@ int psg_noise_fallback_f32(const float* x0, const float* noise, float* out, int3
 int psg_ddpm_update_f32(float* x, const float* eps, const float* z, const float* c1, const float* c2,
                         const float* sigma, const int32_t* t_dev, int64_t n, psg_stream_t stream);
 
+/* Update steps of the two other samplers that consume the trained U-Net, in place on x (fp32, the reference's operation
+ * order, bit-exact):
+ *   mode 1 — NoiseScheduler.sample_previous_timestep, src/training/final_trainer.py:52-71:
+ *            x <- c0 * (x - (c1 * eps) / c2) [+ c3 * z]   with c0 = sqrt(1/alpha_t), c1 = beta_t, c2 = sqrt(1 - abar_t),
+ *            c3 = sqrt(posterior_variance_t); z == NULL for t == 0
+ *   mode 2 — the t == 0 step of FinalPokemonGenerator.forward, final_trainer.py:203:  x <- x - eps
+ *   mode 3 — PokemonGradioGenerator.ddpm_sample, gradio_app.py:343-358:
+ *            x <- (x - c0 * eps) / c1  with c0 = (1 - alpha_t)/sqrt(1 - abar_t), c1 = sqrt(alpha_t); then, when z != NULL
+ *            (not the last step and next_t > 0), x <- c2 * x + c3 * z with c2 = sqrt(alpha_next), c3 = sqrt(1 - alpha_next)
+ * The scalars are computed by the host with the reference's own torch expressions. */
+int psg_sampler_update_f32(float* x, const float* eps, const float* z, int mode, float c0, float c1, float c2,
+                           float c3, int64_t n, psg_stream_t stream);
+
 /* SmoothL1Loss(beta) mean + its gradient — improved_diffusion_trainer.py:300,388,396.
  * loss_out: fp32 device scalar; grad (may be NULL) = dL/dpred * grad_scale.  Deterministic
  * two-stage reduction.  ws: >= psg_reduce_workspace_bytes() bytes. */

@@ -304,3 +304,101 @@ def ddpm_sample(eps_fn, tables, text_emb, x_T, noise_fn, fast_sampling=True, tra
         if trace is not None:
             trace.append(x.clone())
     return x
+
+
+# ---------------------------------------------------------------------------
+# f-3  inference consumers of the trained U-Net
+# ---------------------------------------------------------------------------
+
+
+def final_linear_tables(num_timesteps=1000, beta_start=0.0001, beta_end=0.02):
+    """src/training/final_trainer.py:22-40 - the stage-3 NoiseScheduler: LINEAR betas plus sqrt_recip_alphas and the
+    clamped posterior variance."""
+    betas = torch.linspace(beta_start, beta_end, num_timesteps)
+    alphas = 1.0 - betas
+    alphas_cumprod = torch.cumprod(alphas, dim=0)
+    posterior_variance = betas * (1.0 - torch.cat([torch.tensor([1.0]), alphas_cumprod[:-1]])) / (1.0 - alphas_cumprod)
+    return {
+        "betas": betas, "alphas": alphas, "alphas_cumprod": alphas_cumprod,
+        "sqrt_alphas_cumprod": torch.sqrt(alphas_cumprod),
+        "sqrt_one_minus_alphas_cumprod": torch.sqrt(1.0 - alphas_cumprod),
+        "sqrt_recip_alphas": torch.sqrt(1.0 / alphas),
+        "posterior_variance": torch.clamp(posterior_variance, min=1e-20),
+    }
+
+
+def final_add_noise(x0, noise, t, tables):
+    """final_trainer.py:42-50 (no clamp, no fallback)."""
+    a = tables["sqrt_alphas_cumprod"][t].view(-1, 1, 1, 1)
+    b = tables["sqrt_one_minus_alphas_cumprod"][t].view(-1, 1, 1, 1)
+    return a * x0 + b * noise
+
+
+def sample_previous_timestep(x_t, predicted_noise, timestep, tables, noise=None):
+    """final_trainer.py:52-71: mean = sqrt(1/alpha_t) * (x_t - beta_t * eps / sqrt(1 - abar_t)); for t > 0 plus
+    sqrt(posterior_variance_t) * noise (`noise` is what the reference draws with randn_like)."""
+    sra = tables["sqrt_recip_alphas"][timestep]
+    beta = tables["betas"][timestep]
+    somac = tables["sqrt_one_minus_alphas_cumprod"][timestep]
+    mean = sra * (x_t - beta * predicted_noise / somac)
+    if timestep > 0:
+        return mean + torch.sqrt(tables["posterior_variance"][timestep]) * noise
+    return mean
+
+
+def final_generate_latents(eps_fn, tables, text_emb, x_T, noise_fn, num_inference_steps=50, trace=None):
+    """final_trainer.py:186-204 - the latent loop of FinalPokemonGenerator.forward(mode='generate'): timestep
+    T-1 - i*step_size clamped at 0; sample_previous_timestep for t > 0, `latent - predicted_noise` at t == 0.
+    noise_fn(i, shape) supplies the i-th randn_like draw."""
+    num_t = tables["betas"].shape[0]
+    n = x_T.shape[0]
+    latent = x_T
+    step_size = max(1, num_t // num_inference_steps)
+    draws = 0
+    for i in range(num_inference_steps):
+        timestep = max(0, num_t - 1 - i * step_size)
+        tv = torch.full((n,), timestep, dtype=torch.long)
+        eps = eps_fn(latent, tv, text_emb)
+        if timestep > 0:
+            latent = sample_previous_timestep(latent, eps, timestep, tables, noise_fn(draws, latent.shape))
+            draws += 1
+        else:
+            latent = latent - eps
+        if trace is not None:
+            trace.append(latent.clone())
+    return latent
+
+
+def gradio_tables(num_timesteps=1000, beta_start=0.0001, beta_end=0.02):
+    """gradio_app.py:279-288 (linear betas)."""
+    betas = torch.linspace(beta_start, beta_end, num_timesteps)
+    alphas = 1.0 - betas
+    return {"betas": betas, "alphas": alphas, "alphas_cumprod": torch.cumprod(alphas, dim=0)}
+
+
+def gradio_ddpm_sample(eps_fn, tables, text_emb, x_init, noise_fn, num_inference_steps=50, trace=None):
+    """gradio_app.py:323-361 - the demo's own sampler: timesteps = linspace(T-1, 0, n) truncated to long; per step
+    latent = (latent - (1-alpha_t)/sqrt(1-abar_t) * eps) / sqrt(alpha_t), then (not on the last step, and only if the
+    NEXT timestep is > 0) re-noised: sqrt(alpha_next) * latent + sqrt(1 - alpha_next) * noise."""
+    num_t = tables["betas"].shape[0]
+    n = x_init.shape[0]
+    latent = x_init.clone()
+    timesteps = torch.linspace(num_t - 1, 0, num_inference_steps, dtype=torch.long)
+    alphas, ac = tables["alphas"], tables["alphas_cumprod"]
+    draws = 0
+    for i, t in enumerate(timesteps):
+        tv = torch.full((n,), t.item(), dtype=torch.long)
+        eps = eps_fn(latent, tv, text_emb)
+        if i < len(timesteps) - 1:
+            next_t = timesteps[i + 1]
+            alpha_t, alpha_next = alphas[t], alphas[next_t]
+            latent = (latent - (1 - alpha_t) / torch.sqrt(1 - ac[t]) * eps) / torch.sqrt(alpha_t)
+            if next_t > 0:
+                noise = noise_fn(draws, latent.shape)
+                draws += 1
+                latent = torch.sqrt(alpha_next) * latent + torch.sqrt(1 - alpha_next) * noise
+        else:
+            latent = (latent - (1 - alphas[t]) / torch.sqrt(1 - ac[t]) * eps) / torch.sqrt(alphas[t])
+        if trace is not None:
+            trace.append(latent.clone())
+    return latent

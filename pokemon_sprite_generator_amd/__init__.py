@@ -12,8 +12,9 @@ from .unet import CrossAttentionBlock, ResBlock, TimestepEmbedding, UNet, UNetBl
 from .optim import FusedAdamW, GradArena, ParamArena
 from .ddp import BucketedAllReduce
 from .trainer import DiffusionStepper, DiffusionTrainer, ImprovedDiffusionTrainer
+from .inference import LatentGenerator, LinearNoiseScheduler, gradio_ddpm_sample
 
 __all__ = ["UNet", "UNetBlock", "ResBlock", "CrossAttentionBlock", "TimestepEmbedding", "NoiseScheduler",
            "ImprovedDiffusionTrainer", "DiffusionTrainer", "DiffusionStepper", "FusedAdamW", "GradArena", "ParamArena",
-           "BucketedAllReduce", "PsgError", "LIB_PATH"]
+           "BucketedAllReduce", "LatentGenerator", "LinearNoiseScheduler", "gradio_ddpm_sample", "PsgError", "LIB_PATH"]
 __version__ = "0.1.0"

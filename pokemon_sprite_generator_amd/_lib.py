@@ -55,6 +55,7 @@ SIGNATURES = {
     "psg_noise_add_f32": (c_int, [c_void_p] * 7 + [c_int64, c_int64, c_int, c_int, c_void_p]),
     "psg_noise_fallback_f32": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_void_p]),
     "psg_ddpm_update_f32": (c_int, [c_void_p] * 7 + [c_int64, c_void_p]),
+    "psg_sampler_update_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int] + [c_float] * 4 + [c_int64, c_void_p]),
     "psg_smooth_l1_f32": (c_int, [c_void_p] * 5 + [c_float, c_float, c_int64, c_void_p, c_void_p]),
     "psg_reduce_workspace_bytes": (c_int64, []),
     "psg_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),

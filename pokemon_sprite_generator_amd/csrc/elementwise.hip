@@ -80,6 +80,29 @@ __global__ void ddpm_update_kernel(float* __restrict__ x, const float* __restric
     }
 }
 
+// The other samplers that consume the trained U-Net, each with the reference's own operation order so
+// that fp32 results are bit-identical to the PyTorch CPU path (separately rounded multiply / divide / add, no FMA):
+//   mode 1  final_trainer.py:58-69   mean = c0 * (x - (c1 * eps) / c2)  [+ c3 * z]      sample_previous_timestep
+//   mode 2  final_trainer.py:203     x - eps                                            last step of FinalPokemonGenerator
+//   mode 3  gradio_app.py:349-358    y = (x - c0 * eps) / c1  [; y = c2 * y + c3 * z]   the demo's ddpm_sample
+__global__ void sampler_update_kernel(float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ z,
+                                      int mode, float c0, float c1, float c2, float c3, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float xv = x[i], ev = eps[i];
+        float r;
+        if (mode == 1) {
+            r = __fmul_rn(c0, __fsub_rn(xv, __fdiv_rn(__fmul_rn(c1, ev), c2)));
+            if (z) r = __fadd_rn(r, __fmul_rn(c3, z[i]));
+        } else if (mode == 2) {
+            r = __fsub_rn(xv, ev);
+        } else {
+            r = __fdiv_rn(__fsub_rn(xv, __fmul_rn(c0, ev)), c1);
+            if (z) r = __fadd_rn(__fmul_rn(c2, r), __fmul_rn(c3, z[i]));
+        }
+        x[i] = r;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // deterministic two-stage reductions (fixed grid, fixed order)
 // ---------------------------------------------------------------------------
@@ -614,6 +637,16 @@ int psg_ddpm_update_f32(float* x, const float* eps, const float* z, const float*
     hipLaunchKernelGGL(ddpm_update_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, eps, z, c1, c2,
                        sigma, t_dev, n);
     PSG_LAUNCH_CHECK("ddpm_update");
+    return PSG_OK;
+}
+
+int psg_sampler_update_f32(float* x, const float* eps, const float* z, int mode, float c0, float c1, float c2, float c3,
+                           int64_t n, psg_stream_t stream) {
+    PSG_REQUIRE(x && eps, PSG_ERR_ARG, "sampler_update: null pointer");
+    PSG_REQUIRE(mode >= 1 && mode <= 3, PSG_ERR_ARG, "sampler_update: mode %d", mode);
+    if (n <= 0) return PSG_OK;
+    hipLaunchKernelGGL(sampler_update_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, x, eps, z, mode, c0, c1, c2, c3, n);
+    PSG_LAUNCH_CHECK("sampler_update");
     return PSG_OK;
 }
 

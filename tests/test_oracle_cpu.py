@@ -187,3 +187,28 @@ def test_product_state_dict_layout():
     assert shapes["dec_block0.1.res_block.skip_conv.weight"] == (320, 640, 1, 1)
     assert shapes["middle_block.attn_block.ffn.3.weight"] == (1280, 2560)
     assert "enc_block0.0.attn_block.norm1.weight" not in shapes and "dec_block0.0.attn_block.norm1.weight" not in shapes
+
+
+def test_inference_oracle_golden(golden):
+    """f-3: the oracle's restatement of stage 3's NoiseScheduler (final_trainer.py:19-81) reproduces the outputs of the
+    reference's own class (fixture written by oracle/make_golden_inference.py) bit for bit, and so do the host-side
+    tables of the product's LinearNoiseScheduler (the per-element update itself needs the GPU: tests/test_unet_gpu.py)."""
+    import math
+    import pokemon_sprite_generator_amd as psg
+    from oracle import cases, hashgen
+    g = golden("inference.npz")
+    tb = O.final_linear_tables()
+    sch = psg.LinearNoiseScheduler()
+    for n in ("betas", "alphas", "alphas_cumprod", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "sqrt_recip_alphas",
+              "posterior_variance"):
+        assert np.array_equal(tb[n].numpy(), g["final_" + n]), n
+        assert np.array_equal(getattr(sch, n).numpy(), g["final_" + n]), n
+    x0 = hashgen.uniform((5, 8, 9, 9), cases.INPUT_SEED, hashgen.name_id("fin.x0")) * 2.5
+    nz = hashgen.uniform((5, 8, 9, 9), cases.INPUT_SEED, hashgen.name_id("fin.noise")) * 2.0
+    t = torch.from_numpy(g["final_add_noise_t"])
+    assert np.array_equal(O.final_add_noise(x0, nz, t, tb).numpy(), g["final_add_noise"])
+    for ts in (0, 1, 500, 999):
+        z = hashgen.uniform(tuple(x0.shape), cases.INPUT_SEED, hashgen.name_id(f"spt{ts}.z0")) * math.sqrt(3.0)
+        assert np.array_equal(O.sample_previous_timestep(x0, nz, ts, tb, z).numpy(), g[f"final_prev_t{ts}"]), ts
+    gt = O.gradio_tables()
+    assert torch.equal(gt["betas"], tb["betas"]) and torch.equal(gt["alphas_cumprod"], tb["alphas_cumprod"])

@@ -429,3 +429,71 @@ def test_sampler_trace_golden(psg, golden, full_unets):
     assert len(trace_e) == 20 and torch.equal(xe, x)
     for a, b in zip(trace, trace_e):
         assert torch.equal(a, b)
+
+
+# ------------------------------------------------------------------------- f-3: inference consumers of the trained U-Net
+def _named_noise(tag):
+    def fn(i, shape):
+        nm = f"{tag}.xT" if i < 0 else f"{tag}.z{i}"
+        return hashgen.uniform(tuple(shape), cases.INPUT_SEED, hashgen.name_id(nm)) * math.sqrt(3.0)
+    return fn
+
+
+def test_final_scheduler_bit_exact(psg, golden):
+    """Stage 3's NoiseScheduler (final_trainer.py:19-81): tables, add_noise and sample_previous_timestep against outputs of
+    the reference's own class (AST-extracted, oracle/make_golden_inference.py) - bit for bit."""
+    g = golden("inference.npz")
+    sch = psg.LinearNoiseScheduler()
+    for n in ("betas", "alphas", "alphas_cumprod", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "sqrt_recip_alphas",
+              "posterior_variance"):
+        assert np.array_equal(getattr(sch, n).numpy(), g["final_" + n]), n
+    x0 = hashgen.uniform((5, 8, 9, 9), cases.INPUT_SEED, hashgen.name_id("fin.x0")) * 2.5
+    nz = hashgen.uniform((5, 8, 9, 9), cases.INPUT_SEED, hashgen.name_id("fin.noise")) * 2.0
+    t = torch.from_numpy(g["final_add_noise_t"])
+    assert np.array_equal(sch.add_noise(x0.to(DEV), nz.to(DEV), t.to(DEV)).cpu().numpy(), g["final_add_noise"])
+    for ts in (0, 1, 500, 999):
+        z = _named_noise(f"spt{ts}")(0, x0.shape)
+        got = sch.sample_previous_timestep(x0.to(DEV), nz.to(DEV), ts, noise=z.to(DEV)).cpu()
+        assert np.array_equal(got.numpy(), g[f"final_prev_t{ts}"]), ts
+        want = O.sample_previous_timestep(x0, nz, ts, O.final_linear_tables(), z)          # and the oracle on this host
+        assert torch.equal(got, want)
+
+
+def test_final_generator_latents_golden(psg, golden, full_unets):
+    """FinalPokemonGenerator.forward(mode='generate') latent loop (final_trainer.py:186-204) vs the reference's own method
+    run on the reference U-Net (fixture): 8 strided steps at T=1000, and the T=6 / T=3 schedules that reach the
+    `latent - predicted_noise` branch with a clamped timestep."""
+    g = golden("inference.npz")
+    u, _ = full_unets("stress", 8)
+    u.set_compute_dtype(torch.float32)
+    _, _, text = hashgen.unet_inputs(1, cases.INPUT_SEED)
+    gen = psg.LatentGenerator(u)
+    trace = []
+    x = gen(text.to(DEV), 8, noise_fn=_named_noise("fgen"), trace=trace)
+    assert len(trace) == 8
+    for i in (0, 4, 7):
+        assert maxrel(trace[i], torch.from_numpy(g[f"fgen_step{i}"])) < 5e-3, i       # chained U-Net calls; per-call bar 1e-3
+    assert maxrel(x, torch.from_numpy(g["fgen_final"])) < 5e-3
+    for T, tag in ((6, "fgen0"), (3, "fgen3")):
+        gen = psg.LatentGenerator(u, psg.LinearNoiseScheduler(num_timesteps=T))
+        x = gen(text.to(DEV), 4, noise_fn=_named_noise(tag))
+        assert maxrel(x, torch.from_numpy(g[f"fgen_T{T}_final"])) < 5e-3, T
+
+
+def test_gradio_sampler_golden(psg, golden, full_unets):
+    """PokemonGradioGenerator.ddpm_sample (gradio_app.py:297-361), text-only and from an initial latent, 7 steps."""
+    g = golden("inference.npz")
+    u, _ = full_unets("stress", 8)
+    u.set_compute_dtype(torch.float32)
+    _, _, text = hashgen.unet_inputs(1, cases.INPUT_SEED)
+    for tag in ("grad", "gradimg"):
+        init = None
+        if tag == "gradimg":
+            init = (hashgen.uniform((1, 8, 27, 27), cases.INPUT_SEED, hashgen.name_id("gradimg.init")) * 1.5).to(DEV)
+        trace = []
+        x = psg.gradio_ddpm_sample(u, text.to(DEV), 7, initial_latent=init, noise_fn=_named_noise(tag), trace=trace)
+        for i in (0, 3, 6):
+            assert maxrel(trace[i], torch.from_numpy(g[f"{tag}_step{i}"])) < 5e-3, (tag, i)
+        assert maxrel(x, torch.from_numpy(g[tag + "_final"])) < 5e-3
+        if init is not None:
+            assert not torch.equal(init, x)              # the caller's latent is not written into
