@@ -22,8 +22,11 @@ struct AttnP {
     uint32_t drop_thresh; float drop_scale; uint64_t seed;
 };
 
+// dropout element index of P[bh][l][s]: each query row owns ceil(S/2) hash PAIRS (keys 2k, 2k+1 share one 32-bit hash),
+// exactly as attention_mfma.hip lays them out - so the VALU and the MFMA kernels draw the SAME mask for every S (odd S
+// too: 7x7 self-attention has S = 49) and a forward on one path can be differentiated on the other
 __device__ __forceinline__ uint64_t attn_idx(const AttnP& p, int bh, int l, int s) {
-    return ((uint64_t)bh * p.L + l) * p.S + s;
+    return ((uint64_t)bh * p.L + l) * (uint64_t)(2 * ((p.S + 1) >> 1)) + s;
 }
 
 // stage `rows` rows of d elements (global row r at base + r*ld) into LDS with row stride d+1, scaled
@@ -361,6 +364,13 @@ int psg_attn_init_attrs(void) {
     return PSG_OK;
 }
 
+static int64_t g_attn_paths[2] = {0, 0};            // launches taken by the MFMA / the VALU kernels (tests assert the path)
+int psg_attn_path_counts(int64_t* mfma, int64_t* valu) {
+    if (mfma) *mfma = g_attn_paths[0];
+    if (valu) *valu = g_attn_paths[1];
+    return PSG_OK;
+}
+
 int psg_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv, void* o, int64_t ldo,
                  float* lse, int B, int heads, int L, int S, int d, float scale, float drop_p, uint64_t seed, int dtype,
                  psg_stream_t stream) {
@@ -376,8 +386,11 @@ int psg_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const v
     p.drop_thresh = drop_p > 0.f ? drop_thresh(drop_p) : 0u; p.drop_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f; p.seed = seed;
     dim3 grid((L + AT_Q - 1) / AT_Q, B * heads);
     ProfScope prof(PROF_ATTN, 4.0 * (double)B * heads * L * S * d, (hipStream_t)stream);
-    if (attn_mfma_applicable(L, S, d, dtype, ldq, ldk, ldv, ldo) && aligned16(q) && aligned16(k) && aligned16(v) && aligned8(o))
+    if (attn_mfma_applicable(L, S, d, dtype, ldq, ldk, ldv, ldo) && aligned16(q) && aligned16(k) && aligned16(v) && aligned8(o)) {
+        ++g_attn_paths[0];
         return attn_mfma_fwd(to_mfma(p), (hipStream_t)stream);
+    }
+    ++g_attn_paths[1];
     if (dtype == PSG_F32) hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, p);
     else hipLaunchKernelGGL(attn_fwd_kernel<bf16_t>, grid, dim3(256), lds, (hipStream_t)stream, p);
     PSG_LAUNCH_CHECK("attn_fwd");
@@ -409,8 +422,10 @@ int psg_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const v
     ProfScope prof(PROF_ATTN, 10.0 * (double)B * heads * L * S * d, s);
     if (attn_mfma_applicable(L, S, d, dtype, ldq, ldk, ldv, ldo) && ((lddo | lddq | lddk | lddv) & 7) == 0 && aligned16(q) && aligned16(k) &&
         aligned16(v) && aligned16(o) && aligned16(dout) && aligned8(dq) && aligned8(dk) && aligned8(dv)) {
+        ++g_attn_paths[0];
         return attn_mfma_bwd(to_mfma(p), s);       // (delta is produced inside the dQ kernel)
     }
+    ++g_attn_paths[1];
     if (dtype == PSG_F32) {
         hipLaunchKernelGGL(attn_delta_kernel<float>, dim3(gdelta), dim3(256), 0, s, p);
         hipLaunchKernelGGL(attn_dq_kernel<float>, gq, dim3(256), l1, s, p);

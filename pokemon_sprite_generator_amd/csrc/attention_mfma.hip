@@ -363,9 +363,15 @@ __global__ __launch_bounds__(256, (ND <= 5 ? 2 : 1)) void attn_dkv_mfma(const At
             __builtin_amdgcn_s_waitcnt(0);     // all counters: the wave's own LDS writes have landed
             __builtin_amdgcn_wave_barrier();
         }
-        f32x16 dk[NDT], dv[NDT];
+        // head_dim 320: the 2 x 10 output tiles of dK and dV (320 accumulator registers) do not fit next to the score
+        // tiles, so the head dimension is produced in two halves, each recomputing the (cheap) score / dP tiles
+        constexpr int NH = ND > 10 ? 2 : 1, TH = NDT / NH;
+        static_assert(NDT % NH == 0, "head-dim halves");
+#pragma unroll 1
+        for (int hp = 0; hp < NH; ++hp) {
+        f32x16 dk[TH], dv[TH];
 #pragma unroll
-        for (int t = 0; t < NDT; ++t)
+        for (int t = 0; t < TH; ++t)
 #pragma unroll
             for (int e = 0; e < 16; ++e) { dk[t][e] = 0.f; dv[t][e] = 0.f; }
         for (int qt = 0; qt < nqt; ++qt) {
@@ -408,23 +414,24 @@ __global__ __launch_bounds__(256, (ND <= 5 ? 2 : 1)) void attn_dkv_mfma(const At
             }
             const bf16x8 pf0 = pack8(pd, 0), pf1 = pack8(pd, 1), sf0 = pack8(st, 0), sf1 = pack8(st, 1);
 #pragma unroll
-            for (int t = 0; t < NDT; ++t) {
-                const bf16x8 g0 = tr_frag(Gs, STR, qt * 32, 0, t * 32, lane);
-                const bf16x8 g1 = tr_frag(Gs, STR, qt * 32, 1, t * 32, lane);
+            for (int t = 0; t < TH; ++t) {
+                const int tc = (hp * TH + t) * 32;
+                const bf16x8 g0 = tr_frag(Gs, STR, qt * 32, 0, tc, lane);
+                const bf16x8 g1 = tr_frag(Gs, STR, qt * 32, 1, tc, lane);
                 dv[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g0, pf0, dv[t], 0, 0, 0);   // dV^T[d][key] += dO^T . P
                 dv[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(g1, pf1, dv[t], 0, 0, 0);
-                const bf16x8 q0 = tr_frag(Qs, STR, qt * 32, 0, t * 32, lane);
-                const bf16x8 q1 = tr_frag(Qs, STR, qt * 32, 1, t * 32, lane);
+                const bf16x8 q0 = tr_frag(Qs, STR, qt * 32, 0, tc, lane);
+                const bf16x8 q1 = tr_frag(Qs, STR, qt * 32, 1, tc, lane);
                 dk[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q0, sf0, dk[t], 0, 0, 0);   // dK^T[d][key] += Q^T . dS
                 dk[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1, sf1, dk[t], 0, 0, 0);
             }
         }
         if (kok) {
 #pragma unroll
-            for (int t = 0; t < NDT; ++t)
+            for (int t = 0; t < TH; ++t)
 #pragma unroll
                 for (int g4 = 0; g4 < 4; ++g4) {
-                    const int dd = t * 32 + 8 * g4 + 4 * fh;
+                    const int dd = (hp * TH + t) * 32 + 8 * g4 + 4 * fh;
                     if (dd < d) {
                         f32x4 a = {dk[t][4 * g4], dk[t][4 * g4 + 1], dk[t][4 * g4 + 2], dk[t][4 * g4 + 3]};
                         f32x4 c = {dv[t][4 * g4], dv[t][4 * g4 + 1], dv[t][4 * g4 + 2], dv[t][4 * g4 + 3]};
@@ -433,21 +440,30 @@ __global__ __launch_bounds__(256, (ND <= 5 ? 2 : 1)) void attn_dkv_mfma(const At
                     }
                 }
         }
+        }   // hp
         __builtin_amdgcn_wave_barrier();    // tile reads done before the next restage (same wave, program order)
     }
 }
 
-static inline int nd_supported(int d) { return d == 16 || d == 32 || d == 80 || d == 160; }
+static inline int nd_supported(int d) { return d == 16 || d == 32 || d == 80 || d == 160 || d == 320; }
 static inline size_t str_bytes(int d) { return 2 * (size_t)d + 16; }
 static inline size_t fwd_lds_m(int S, int d) { return 2 * (size_t)((S + 31) & ~31) * str_bytes(d) + 32; }
 // one wave per 32-row tile of the loop the waves share (queries for fwd/dQ, keys for dK/dV), at most 4: a 7x7 map
 // (49 rows) gets 2 waves per workgroup instead of 4 half-idle ones, and twice the workgroups fit a CU
 static inline int attn_waves(int rows) { const int t = (rows + 31) / 32; return t < 1 ? 1 : (t > 4 ? 4 : t); }
-static inline size_t dkv_lds_m(int L, int S, int d) {
-    const size_t Lp = (L + 31) & ~31;
-    return 2 * Lp * str_bytes(d) + 32 + (d > 80 ? (size_t)attn_waves(S) * 2 * 32 * str_bytes(d) + 32 : 0);
-}
 constexpr size_t MFMA_LDS_CAP = 158 * 1024;
+static inline size_t dkv_lds_w(int L, int d, int waves) {
+    const size_t Lp = (L + 31) & ~31;
+    return 2 * Lp * str_bytes(d) + 32 + (d > 80 ? (size_t)waves * 2 * 32 * str_bytes(d) + 32 : 0);
+}
+// waves of the dK/dV kernel: one per 32-key tile, fewer when their private K/V tiles would not fit LDS next to the
+// Q / dO images (head_dim 320 = the reference CLI's 4 heads at 1280 channels: 7x7 self-attention runs 1 wave)
+static inline int dkv_waves(int L, int S, int d) {
+    int w = attn_waves(S);
+    while (w > 1 && dkv_lds_w(L, d, w) > MFMA_LDS_CAP) --w;
+    return w;
+}
+static inline size_t dkv_lds_m(int L, int S, int d) { return dkv_lds_w(L, d, dkv_waves(L, S, d)); }
 
 // returns 1 when the MFMA path handles this problem
 int attn_mfma_applicable(int L, int S, int d, int dtype, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo) {
@@ -462,14 +478,15 @@ int attn_mfma_applicable(int L, int S, int d, int dtype, int64_t ldq, int64_t ld
         case 16: hipLaunchKernelGGL(KERNEL<1>, __VA_ARGS__); break;                                   \
         case 32: hipLaunchKernelGGL(KERNEL<2>, __VA_ARGS__); break;                                   \
         case 80: hipLaunchKernelGGL(KERNEL<5>, __VA_ARGS__); break;                                   \
-        default: hipLaunchKernelGGL(KERNEL<10>, __VA_ARGS__); break;                                  \
+        case 160: hipLaunchKernelGGL(KERNEL<10>, __VA_ARGS__); break;                                 \
+        default: hipLaunchKernelGGL(KERNEL<20>, __VA_ARGS__); break;                                  \
     }
 
 int attn_mfma_init_attrs() {
 #define SET_LDS(K) PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MFMA_LDS_CAP))
-    SET_LDS(attn_fwd_mfma<1>); SET_LDS(attn_fwd_mfma<2>); SET_LDS(attn_fwd_mfma<5>); SET_LDS(attn_fwd_mfma<10>);
-    SET_LDS(attn_dq_mfma<1>); SET_LDS(attn_dq_mfma<2>); SET_LDS(attn_dq_mfma<5>); SET_LDS(attn_dq_mfma<10>);
-    SET_LDS(attn_dkv_mfma<1>); SET_LDS(attn_dkv_mfma<2>); SET_LDS(attn_dkv_mfma<5>); SET_LDS(attn_dkv_mfma<10>);
+    SET_LDS(attn_fwd_mfma<1>); SET_LDS(attn_fwd_mfma<2>); SET_LDS(attn_fwd_mfma<5>); SET_LDS(attn_fwd_mfma<10>); SET_LDS(attn_fwd_mfma<20>);
+    SET_LDS(attn_dq_mfma<1>); SET_LDS(attn_dq_mfma<2>); SET_LDS(attn_dq_mfma<5>); SET_LDS(attn_dq_mfma<10>); SET_LDS(attn_dq_mfma<20>);
+    SET_LDS(attn_dkv_mfma<1>); SET_LDS(attn_dkv_mfma<2>); SET_LDS(attn_dkv_mfma<5>); SET_LDS(attn_dkv_mfma<10>); SET_LDS(attn_dkv_mfma<20>);
 #undef SET_LDS
     return PSG_OK;
 }
@@ -484,7 +501,7 @@ int attn_mfma_bwd(const AttnMP& p, hipStream_t s) {
     const int d = p.d;
     ND_DISPATCH(attn_dq_mfma, dim3(p.B * p.H), dim3(64 * attn_waves(p.L)), fwd_lds_m(p.S, d), s, p);
     PSG_LAUNCH_CHECK("attn_dq_mfma");
-    ND_DISPATCH(attn_dkv_mfma, dim3(p.B * p.H), dim3(64 * attn_waves(p.S)), dkv_lds_m(p.L, p.S, d), s, p);
+    ND_DISPATCH(attn_dkv_mfma, dim3(p.B * p.H), dim3(64 * dkv_waves(p.L, p.S, d)), dkv_lds_m(p.L, p.S, d), s, p);
     PSG_LAUNCH_CHECK("attn_dkv_mfma");
     return PSG_OK;
 }

@@ -395,6 +395,8 @@ def test_conv_linearity_full_size(psg):
 ATTN_CASES = [  # B, heads, L, S, d, self
     (2, 8, 16, 16, 16, True), (2, 4, 49, 49, 32, True), (1, 8, 196, 196, 80, True), (2, 8, 16, 32, 160, False),
     (2, 8, 196, 32, 80, False), (1, 4, 49, 20, 320, False), (1, 8, 49, 32, 160, False),
+    # the reference CLI's real head count: 4 heads at 1280 channels -> head_dim 320 (improved_diffusion_trainer.py:215)
+    (2, 4, 49, 49, 320, True), (2, 4, 16, 16, 320, True), (2, 4, 16, 32, 320, False), (1, 4, 49, 32, 320, False),
 ]
 
 
@@ -438,6 +440,49 @@ def test_attention(psg, dtype, B, heads, L, S, d, self_mode):
         assert maxrel(o.float().cpu(), ref) < tol
         assert maxrel(qd.grad.float().cpu(), qs.grad) < tol * 2
         assert maxrel(kd.grad.float().cpu(), kv.grad) < tol * 2
+
+
+def _attn_paths():
+    from pokemon_sprite_generator_amd import _lib
+    a, b = C.c_int64(0), C.c_int64(0)
+    _lib.check(_lib.init(0).psg_attn_path_counts(C.byref(a), C.byref(b)), "psg_attn_path_counts")
+    return a.value, b.value
+
+
+@pytest.mark.parametrize("d", [16, 32, 80, 160, 320])
+def test_attention_bf16_takes_the_mfma_kernels(psg, d):
+    """bf16 attention at every head_dim the U-Net produces (8 heads: 80 / 160; the CLI's 4 heads: 160 / 320) must run on
+    the matrix cores, forward and backward; fp32 runs the VALU kernels."""
+    from pokemon_sprite_generator_amd import ops
+    heads, L = 4, 49
+    qkv = h((2, L, 3 * heads * d), f"path{d}", 1.0)
+    for dtype, col in ((torch.bfloat16, 0), (torch.float32, 1)):
+        before = _attn_paths()
+        x = qkv.to(dtype).to(DEV).requires_grad_(True)
+        ops.attention_self(x, heads).sum().backward()
+        after = _attn_paths()
+        assert after[col] - before[col] == 2 and after[1 - col] == before[1 - col], (dtype, before, after)
+
+
+@pytest.mark.parametrize("S", [49, 20, 32])
+def test_attention_dropout_mask_is_path_independent(psg, S):
+    """The VALU (fp32) and MFMA (bf16) kernels regenerate the SAME stateless dropout mask from (seed, row, key) - for odd
+    S too (7x7 self-attention: S = 49) - so a forward on one path can be differentiated on the other.  With q = k = 0 and
+    v = key one-hot columns, output column j of a query row is (1/S)/(1-p) where key j was kept and 0 where it was dropped."""
+    from pokemon_sprite_generator_amd import ops
+    B, heads, L, d, p = 2, 2, 49, 80, 0.3
+    E = heads * d
+    q = torch.zeros(B, L, E)
+    kv = torch.zeros(B, S, 2 * E)
+    for hh in range(heads):
+        for j in range(S):
+            kv[:, j, E + hh * d + j] = 1.0           # v[key j] = e_j inside each head
+    o32 = ops.attention_cross(q.to(DEV), kv.to(DEV), heads, p, 987).cpu()
+    o16 = ops.attention_cross(q.bfloat16().to(DEV), kv.bfloat16().to(DEV), heads, p, 987).float().cpu()
+    keep32 = o32.view(B, L, heads, d)[..., :S] > 0
+    keep16 = o16.view(B, L, heads, d)[..., :S] > 0
+    assert 0.55 < float(keep32.float().mean()) < 0.85            # p = 0.3 really drops
+    assert torch.equal(keep32, keep16)
 
 
 def test_attention_softmax_spike(psg):

@@ -199,10 +199,12 @@ def test_inference_oracle_golden(golden):
     g = golden("inference.npz")
     tb = O.final_linear_tables()
     sch = psg.LinearNoiseScheduler()
-    for n in ("betas", "alphas", "alphas_cumprod", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "sqrt_recip_alphas",
-              "posterior_variance"):
-        assert np.array_equal(tb[n].numpy(), g["final_" + n]), n
-        assert np.array_equal(getattr(sch, n).numpy(), g["final_" + n]), n
+    names = ("betas", "alphas", "alphas_cumprod", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod", "sqrt_recip_alphas",
+             "posterior_variance")
+    for n in names:      # (torch's vectorised CPU linspace / sqrt differ in the last bit between host CPUs: 1 ulp)
+        assert np.allclose(tb[n].numpy(), g["final_" + n], rtol=4e-7, atol=0), n
+        assert torch.equal(getattr(sch, n), tb[n]), n            # product tables == oracle tables on this host, bit for bit
+    tb = {n: torch.from_numpy(g["final_" + n]) for n in names}  # bit-exact checks below run on the fixture's tables
     x0 = hashgen.uniform((5, 8, 9, 9), cases.INPUT_SEED, hashgen.name_id("fin.x0")) * 2.5
     nz = hashgen.uniform((5, 8, 9, 9), cases.INPUT_SEED, hashgen.name_id("fin.noise")) * 2.0
     t = torch.from_numpy(g["final_add_noise_t"])
@@ -210,5 +212,5 @@ def test_inference_oracle_golden(golden):
     for ts in (0, 1, 500, 999):
         z = hashgen.uniform(tuple(x0.shape), cases.INPUT_SEED, hashgen.name_id(f"spt{ts}.z0")) * math.sqrt(3.0)
         assert np.array_equal(O.sample_previous_timestep(x0, nz, ts, tb, z).numpy(), g[f"final_prev_t{ts}"]), ts
-    gt = O.gradio_tables()
-    assert torch.equal(gt["betas"], tb["betas"]) and torch.equal(gt["alphas_cumprod"], tb["alphas_cumprod"])
+    gt, here = O.gradio_tables(), O.final_linear_tables()
+    assert torch.equal(gt["betas"], here["betas"]) and torch.equal(gt["alphas_cumprod"], here["alphas_cumprod"])
