@@ -14,8 +14,10 @@ Mirrors of the two other samplers in the reference that load a stage-2 checkpoin
 Every schedule scalar is computed on the host with the reference's own torch expressions; the per-element update runs in
 `psg_sampler_update_f32` with the reference's operation order (bit-exact against the CPU path for a given eps).
 """
+import math
 from typing import Callable, Optional
 
+import numpy as np
 import torch
 
 from . import _lib
@@ -26,6 +28,16 @@ def _lib_for(t):
     if not t.is_cuda:
         raise _lib.PsgError("the samplers need GPU tensors (HIP path only; no CPU fallback)")
     return _lib.init(t.device.index if t.device.index is not None else torch.cuda.current_device())
+
+
+def _f32(v):
+    return np.float32(float(v))
+
+
+def _sqrt32(v):
+    """Correctly rounded fp32 square root of an fp32 scalar (double sqrt, one rounding).  torch's vectorised CPU sqrt is
+    not the same function on every host CPU (last bit); the per-step scalars must not depend on the host."""
+    return np.float32(math.sqrt(float(v)))
 
 
 def _update(x, eps, z, mode, c0=0.0, c1=1.0, c2=0.0, c3=0.0):
@@ -86,7 +98,7 @@ class LinearNoiseScheduler:
         z = None
         if t > 0:
             z = noise if noise is not None else torch.randn_like(x)
-        sv = float(torch.sqrt(self.posterior_variance[t])) if t > 0 else 0.0
+        sv = float(_sqrt32(self.posterior_variance[t])) if t > 0 else 0.0
         return _update(x, predicted_noise, z, 1, float(self.sqrt_recip_alphas[t]), float(self.betas[t]),
                        float(self.sqrt_one_minus_alphas_cumprod[t]), sv)
 
@@ -151,15 +163,18 @@ def gradio_ddpm_sample(unet, text_emb: torch.Tensor, num_inference_steps: int = 
     for i, t in enumerate(timesteps):
         tv = torch.full((B,), t.item(), dtype=torch.long, device=dev)
         eps = unet(latent, tv, text_emb)
-        k0 = float((1 - alphas[t]) / torch.sqrt(1 - alphas_cumprod[t]))
-        k1 = float(torch.sqrt(alphas[t]))
+        one = np.float32(1.0)                                   # fp32 scalar arithmetic, as the reference's 0-d tensors
+        a_t, ac_t = _f32(alphas[t]), _f32(alphas_cumprod[t])
+        k0 = float((one - a_t) / _sqrt32(one - ac_t))
+        k1 = float(_sqrt32(a_t))
         z, c2, c3 = None, 0.0, 0.0
         if i < len(timesteps) - 1:
             next_t = timesteps[i + 1]
             if next_t > 0:
                 z = rnd(draws, tuple(latent.shape))
                 draws += 1
-                c2, c3 = float(torch.sqrt(alphas[next_t])), float(torch.sqrt(1 - alphas[next_t]))
+                a_n = _f32(alphas[next_t])
+                c2, c3 = float(_sqrt32(a_n)), float(_sqrt32(one - a_n))
         _update(latent, eps, z, 3, k0, k1, c2, c3)
         if trace is not None:
             trace.append(latent.clone())

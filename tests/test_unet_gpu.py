@@ -472,7 +472,9 @@ def test_final_scheduler_bit_exact(psg, golden):
         z = _named_noise(f"spt{ts}")(0, x0.shape)
         got = sch.sample_previous_timestep(x0.to(DEV), nz.to(DEV), ts, noise=z.to(DEV)).cpu()
         assert np.array_equal(got.numpy(), g[f"final_prev_t{ts}"]), ts
-        assert torch.equal(got, O.sample_previous_timestep(x0, nz, ts, tb, z))             # and the oracle on this host
+        # the oracle evaluated on THIS host takes torch.sqrt(variance) like the reference, which is not the same function
+        # on every host CPU (last bit; the product uses the correctly rounded root): equal to one ulp
+        assert maxrel(got, O.sample_previous_timestep(x0, nz, ts, tb, z)) < 3e-7
 
 
 def test_final_generator_latents_golden(psg, golden, full_unets):
