@@ -47,7 +47,7 @@ enum psg_status {
     PSG_ERR_ARG = -6
 };
 enum psg_dtype { PSG_F32 = 0, PSG_BF16 = 1 };
-enum psg_act { PSG_ACT_NONE = 0, PSG_ACT_SILU = 1, PSG_ACT_GELU = 2 };
+enum psg_act { PSG_ACT_NONE = 0, PSG_ACT_SILU = 1, PSG_ACT_GELU = 2, PSG_ACT_RELU = 3, PSG_ACT_TANH = 4 };   /* RELU / TANH: the frozen VAE (vae_decoder.py:82-91,185) */
 /* Bits of the device-side NaN/Inf flag word of one train step (the reference's five host-side
  * check_for_nans scans, improved_diffusion_trainer.py:353-393).  A step whose word has any bit of
  * PSG_FLAG_SKIP_MASK set is skipped like the reference's `continue`: no optimizer step, no scheduler
@@ -104,6 +104,9 @@ int psg_ddpm_update_f32(float* x, const float* eps, const float* z, const float*
  * The scalars are computed by the host with the reference's own torch expressions. */
 int psg_sampler_update_f32(float* x, const float* eps, const float* z, int mode, float c0, float c1, float c2,
                            float c3, int64_t n, psg_stream_t stream);
+
+/* VAE reparameterisation, src/models/vae_decoder.py:120-123: out = mu + eps * exp(0.5 * logvar) (fp32, separately rounded). */
+int psg_reparam_f32(const float* mu, const float* logvar, const float* eps, float* out, int64_t n, psg_stream_t stream);
 
 /* SmoothL1Loss(beta) mean + its gradient — improved_diffusion_trainer.py:300,388,396.
  * loss_out: fp32 device scalar; grad (may be NULL) = dL/dpred * grad_scale.  Deterministic
@@ -186,7 +189,7 @@ typedef struct psg_conv_desc {
     int32_t dtype;               /* psg_dtype of x, w, y, rowadd, residual, preact, dact_u */
     int32_t B, Hi, Wi, Cin;      /* gather source x: [B, Hi, Wi, Cin] */
     int32_t Ho, Wo, Cout;        /* result y: [B, Ho, Wo, Cout] */
-    int32_t ksize, stride, pad;  /* 1 or 3; 1 or 2; 0 or 1 */
+    int32_t ksize, stride, pad;  /* 1 (pad 0), 3 (pad 1), or the VAE encoder's 4 (stride 2, pad 1 or 2: forward gather only); stride 1 or 2 */
     int32_t transposed;          /* 0 forward gather, 1 data-gradient gather */
     int32_t act;                 /* psg_act applied to (acc + bias + rowadd) */
     float alpha;                 /* scale of the activated value (gates 0.7/0.8/0.6: unet.py:220,238,250) */

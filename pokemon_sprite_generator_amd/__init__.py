@@ -13,8 +13,9 @@ from .optim import FusedAdamW, GradArena, ParamArena
 from .ddp import BucketedAllReduce
 from .trainer import DiffusionStepper, DiffusionTrainer, ImprovedDiffusionTrainer
 from .inference import LatentGenerator, LinearNoiseScheduler, gradio_ddpm_sample
+from .vae import PokemonVAE, VAEDecoder, VAEEncoder
 
 __all__ = ["UNet", "UNetBlock", "ResBlock", "CrossAttentionBlock", "TimestepEmbedding", "NoiseScheduler",
            "ImprovedDiffusionTrainer", "DiffusionTrainer", "DiffusionStepper", "FusedAdamW", "GradArena", "ParamArena",
-           "BucketedAllReduce", "LatentGenerator", "LinearNoiseScheduler", "gradio_ddpm_sample", "PsgError", "LIB_PATH"]
+           "BucketedAllReduce", "LatentGenerator", "LinearNoiseScheduler", "gradio_ddpm_sample", "PokemonVAE", "VAEEncoder", "VAEDecoder", "PsgError", "LIB_PATH"]
 __version__ = "0.1.0"

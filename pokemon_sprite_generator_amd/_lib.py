@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("PSG_LIB_PATH") or os.path.join(_HERE, "libpsg_hip.so")   # override: A/B kernel builds in one GPU session
 
 PSG_F32, PSG_BF16 = 0, 1
-ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_GELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3, 4
 CONV_SAVE_DACT, CONV_DACT_MUL = 1, 2          # enum psg_conv_flags
 # enum psg_flag: bits of the per-step NaN/Inf flag word
 FLAG_NOISY_BAD, FLAG_T_RANGE, FLAG_PRED_BAD, FLAG_LOSS_BAD, FLAG_FALLBACK, FLAG_INPUT_BAD, FLAG_SKIP_MASK = 1, 2, 4, 8, 16, 32, 47
@@ -56,6 +56,7 @@ SIGNATURES = {
     "psg_noise_fallback_f32": (c_int, [c_void_p] * 4 + [c_int64, c_int, c_void_p]),
     "psg_ddpm_update_f32": (c_int, [c_void_p] * 7 + [c_int64, c_void_p]),
     "psg_sampler_update_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int] + [c_float] * 4 + [c_int64, c_void_p]),
+    "psg_reparam_f32": (c_int, [c_void_p] * 4 + [c_int64, c_void_p]),
     "psg_smooth_l1_f32": (c_int, [c_void_p] * 5 + [c_float, c_float, c_int64, c_void_p, c_void_p]),
     "psg_reduce_workspace_bytes": (c_int64, []),
     "psg_nchw_to_nhwc": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_void_p]),

@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256, (ND <= 5 ? 2 : 1)) void attn_dkv_mfma(const At
     }
 }
 
-static inline int nd_supported(int d) { return d == 16 || d == 32 || d == 80 || d == 160 || d == 320; }
+static inline int nd_supported(int d) { return d == 16 || d == 32 || d == 64 || d == 80 || d == 160 || d == 320; }
 static inline size_t str_bytes(int d) { return 2 * (size_t)d + 16; }
 static inline size_t fwd_lds_m(int S, int d) { return 2 * (size_t)((S + 31) & ~31) * str_bytes(d) + 32; }
 // one wave per 32-row tile of the loop the waves share (queries for fwd/dQ, keys for dK/dV), at most 4: a 7x7 map
@@ -477,6 +477,7 @@ int attn_mfma_applicable(int L, int S, int d, int dtype, int64_t ldq, int64_t ld
     switch (d) {                                                                                      \
         case 16: hipLaunchKernelGGL(KERNEL<1>, __VA_ARGS__); break;                                   \
         case 32: hipLaunchKernelGGL(KERNEL<2>, __VA_ARGS__); break;                                   \
+        case 64: hipLaunchKernelGGL(KERNEL<4>, __VA_ARGS__); break;                                   \
         case 80: hipLaunchKernelGGL(KERNEL<5>, __VA_ARGS__); break;                                   \
         case 160: hipLaunchKernelGGL(KERNEL<10>, __VA_ARGS__); break;                                 \
         default: hipLaunchKernelGGL(KERNEL<20>, __VA_ARGS__); break;                                  \
@@ -484,9 +485,9 @@ int attn_mfma_applicable(int L, int S, int d, int dtype, int64_t ldq, int64_t ld
 
 int attn_mfma_init_attrs() {
 #define SET_LDS(K) PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, (int)MFMA_LDS_CAP))
-    SET_LDS(attn_fwd_mfma<1>); SET_LDS(attn_fwd_mfma<2>); SET_LDS(attn_fwd_mfma<5>); SET_LDS(attn_fwd_mfma<10>); SET_LDS(attn_fwd_mfma<20>);
-    SET_LDS(attn_dq_mfma<1>); SET_LDS(attn_dq_mfma<2>); SET_LDS(attn_dq_mfma<5>); SET_LDS(attn_dq_mfma<10>); SET_LDS(attn_dq_mfma<20>);
-    SET_LDS(attn_dkv_mfma<1>); SET_LDS(attn_dkv_mfma<2>); SET_LDS(attn_dkv_mfma<5>); SET_LDS(attn_dkv_mfma<10>); SET_LDS(attn_dkv_mfma<20>);
+    SET_LDS(attn_fwd_mfma<1>); SET_LDS(attn_fwd_mfma<2>); SET_LDS(attn_fwd_mfma<4>); SET_LDS(attn_fwd_mfma<5>); SET_LDS(attn_fwd_mfma<10>); SET_LDS(attn_fwd_mfma<20>);
+    SET_LDS(attn_dq_mfma<1>); SET_LDS(attn_dq_mfma<2>); SET_LDS(attn_dq_mfma<4>); SET_LDS(attn_dq_mfma<5>); SET_LDS(attn_dq_mfma<10>); SET_LDS(attn_dq_mfma<20>);
+    SET_LDS(attn_dkv_mfma<1>); SET_LDS(attn_dkv_mfma<2>); SET_LDS(attn_dkv_mfma<4>); SET_LDS(attn_dkv_mfma<5>); SET_LDS(attn_dkv_mfma<10>); SET_LDS(attn_dkv_mfma<20>);
 #undef SET_LDS
     return PSG_OK;
 }

@@ -636,7 +636,9 @@ int psg_conv_fwd(const psg_conv_desc* d, psg_stream_t stream) {
     const int CH = d->dtype == PSG_BF16 ? 8 : 4;
     PSG_REQUIRE(d->B > 0 && d->Hi > 0 && d->Wi > 0 && d->Cin > 0 && d->Ho > 0 && d->Wo > 0 && d->Cout > 0, PSG_ERR_SHAPE,
                 "conv_fwd: non-positive dimension");
-    PSG_REQUIRE((d->ksize == 1 && d->pad == 0) || (d->ksize == 3 && d->pad == 1), PSG_ERR_SHAPE, "conv_fwd: ksize/pad %d/%d", d->ksize, d->pad);
+    PSG_REQUIRE((d->ksize == 1 && d->pad == 0) || (d->ksize == 3 && d->pad == 1) ||
+                (d->ksize == 4 && (d->pad == 1 || d->pad == 2) && d->stride == 2 && !d->transposed),
+                PSG_ERR_SHAPE, "conv_fwd: ksize/pad/stride %d/%d/%d", d->ksize, d->pad, d->stride);
     PSG_REQUIRE(d->stride == 1 || d->stride == 2, PSG_ERR_SHAPE, "conv_fwd: stride %d", d->stride);
     PSG_REQUIRE(d->Cin % CH == 0, PSG_ERR_SHAPE, "conv_fwd: Cin=%d must be a multiple of %d", d->Cin, CH);
     PSG_REQUIRE(d->Cout % 4 == 0, PSG_ERR_SHAPE, "conv_fwd: Cout=%d must be a multiple of 4", d->Cout);

@@ -650,6 +650,20 @@ int psg_sampler_update_f32(float* x, const float* eps, const float* z, int mode,
     return PSG_OK;
 }
 
+__global__ void reparam_kernel(const float* __restrict__ mu, const float* __restrict__ logvar, const float* __restrict__ eps,
+                               float* __restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = __fadd_rn(mu[i], __fmul_rn(eps[i], expf(__fmul_rn(0.5f, logvar[i]))));
+}
+
+int psg_reparam_f32(const float* mu, const float* logvar, const float* eps, float* out, int64_t n, psg_stream_t stream) {
+    PSG_REQUIRE(mu && logvar && eps && out, PSG_ERR_ARG, "reparam: null pointer");
+    if (n <= 0) return PSG_OK;
+    hipLaunchKernelGGL(reparam_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, mu, logvar, eps, out, n);
+    PSG_LAUNCH_CHECK("reparam");
+    return PSG_OK;
+}
+
 int64_t psg_reduce_workspace_bytes(void) { return (int64_t)RED_BLOCKS * sizeof(float); }
 
 int psg_smooth_l1_f32(const float* pred, const float* target, float* grad, float* loss_out, int32_t* nan_flag,
@@ -851,7 +865,9 @@ int64_t psg_kpad(int64_t K, int dtype) {
 
 int psg_prep_weight(const void* w, int w_dtype, int w_layout, void* wf, void* wd, int O, int I, int ksize, int dtype, psg_stream_t stream) {
     PSG_REQUIRE(w && (wf || wd), PSG_ERR_ARG, "prep_weight: null pointer");
-    PSG_REQUIRE(O > 0 && I > 0 && (ksize == 1 || ksize == 3), PSG_ERR_SHAPE, "prep_weight: O=%d I=%d k=%d", O, I, ksize);
+    PSG_REQUIRE(O > 0 && I > 0 && (ksize == 1 || ksize == 3 || ksize == 4), PSG_ERR_SHAPE, "prep_weight: O=%d I=%d k=%d", O, I, ksize);
+    PSG_REQUIRE(ksize != 4 || (w_layout == PSG_W_OHWI && O % 4 == 0 && I % 4 == 0 && aligned16(w)), PSG_ERR_ARG,
+                "prep_weight: 4x4 weights (VAE encoder) must be OHWI, 16-byte aligned, O and I multiples of 4");
     PSG_REQUIRE(w_layout == PSG_W_OIHW || w_layout == PSG_W_OHWI, PSG_ERR_ARG, "prep_weight: w_layout %d", w_layout);
     PSG_REQUIRE(w_dtype == PSG_F32 || w_dtype == PSG_BF16, PSG_ERR_DTYPE, "prep_weight: w_dtype %d", w_dtype);
     const int ohwi = w_layout == PSG_W_OHWI;

@@ -115,12 +115,18 @@ __device__ __forceinline__ void act_both(float x, int act, float& y, float& dy) 
         const float s = sigmoidf_(x);
         y = x * s;
         dy = s * (1.0f + x * (1.0f - s));
+    } else if (act == PSG_ACT_RELU) {
+        y = fmaxf(x, 0.f); dy = x > 0.f ? 1.0f : 0.f;
+    } else if (act == PSG_ACT_TANH) {
+        y = tanhf(x); dy = 1.0f - y * y;
     } else { y = x; dy = 1.0f; }
 }
 __device__ __forceinline__ float act_f(float x, int act) {
-    return act == PSG_ACT_SILU ? silu_f(x) : (act == PSG_ACT_GELU ? gelu_f(x) : x);
+    return act == PSG_ACT_SILU ? silu_f(x) : (act == PSG_ACT_GELU ? gelu_f(x) : (act == PSG_ACT_RELU ? fmaxf(x, 0.f) : (act == PSG_ACT_TANH ? tanhf(x) : x)));
 }
 __device__ __forceinline__ float act_grad(float x, int act) {
+    if (act == PSG_ACT_RELU) return x > 0.f ? 1.0f : 0.f;
+    if (act == PSG_ACT_TANH) { const float t = tanhf(x); return 1.0f - t * t; }
     return act == PSG_ACT_SILU ? silu_grad(x) : (act == PSG_ACT_GELU ? gelu_grad(x) : 1.0f);
 }
 

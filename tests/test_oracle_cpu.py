@@ -214,3 +214,25 @@ def test_inference_oracle_golden(golden):
         assert np.array_equal(O.sample_previous_timestep(x0, nz, ts, tb, z).numpy(), g[f"final_prev_t{ts}"]), ts
     gt, here = O.gradio_tables(), O.final_linear_tables()
     assert torch.equal(gt["betas"], here["betas"]) and torch.equal(gt["alphas_cumprod"], here["alphas_cumprod"])
+
+
+def test_vae_oracle_golden(golden):
+    """f-4: the VAE oracle (oracle/vae_oracle.py) reproduces the reference module's outputs (fixture written by
+    oracle/make_golden_vae.py from src/models/vae_decoder.py itself): encoder tensors and the small attention-block pins."""
+    from oracle import vae_oracle as V
+    from oracle.make_golden_vae import SEED_IN, SEED_W, vae_inputs
+    import pokemon_sprite_generator_amd as psg
+    g = golden("vae.npz")
+    enc = psg.VAEEncoder(3, 8)                                   # parameter container: names / shapes of the reference
+    esd = hashgen.fill_unet_state({k: tuple(v.shape) for k, v in enc.state_dict().items()}, SEED_W, "stress")
+    img, eps, _, _ = vae_inputs()
+    torch.set_num_threads(8)
+    lat, mu, lv = V.vae_encode(esd, img, eps)
+    for got, name in ((mu, "enc_mu"), (lv, "enc_logvar"), (lat, "enc_latent")):
+        assert maxrel(got, torch.from_numpy(g[name])) < 1e-5, name
+    for c in (512, 32):
+        blk = psg.vae.CrossAttentionBlock(c, 256)
+        bsd = hashgen.fill_unet_state({"ab." + k: tuple(v.shape) for k, v in blk.state_dict().items()}, SEED_W + 2, "stress")
+        x = hashgen.uniform((2, c, 6, 5), SEED_IN, hashgen.name_id(f"vae.ab{c}.x")) * 1.5
+        tx = hashgen.uniform((2, 20, 256), SEED_IN, hashgen.name_id(f"vae.ab{c}.t")) * 1.5
+        assert maxrel(V.cross_attention_block(x, tx, bsd, "ab."), torch.from_numpy(g[f"attn{c}_y"])) < 1e-5
