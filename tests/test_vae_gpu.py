@@ -62,8 +62,9 @@ def test_vae_encoder_golden(psg, golden, dtype):
     else:
         for got, name in ((mu, "enc_mu"), (logvar, "enc_logvar"), (latent, "enc_latent")):
             assert rel_l2(got, torch.from_numpy(g[name])) < 3e-2, name
-    # the sample really is mu + eps * exp(0.5 logvar) of ITS OWN mu / logvar, bit for bit (vae_decoder.py:120-123)
-    assert torch.equal(latent.cpu(), mu.cpu() + eps * torch.exp(0.5 * logvar.cpu()))
+    # the sample really is mu + eps * exp(0.5 logvar) of ITS OWN mu / logvar (vae_decoder.py:120-123; device expf vs the
+    # host's exp: last-bit differences only)
+    assert maxrel(latent.cpu(), mu.cpu() + eps * torch.exp(0.5 * logvar.cpu())) < 1e-6
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
