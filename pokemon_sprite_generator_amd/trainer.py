@@ -8,10 +8,11 @@ the north-star names: `train_step(latents, text_emb, t, noise=None)` (the loop
 body :363-413) and `sample(text_emb, num_samples, fast_sampling, noise_fn=None)`
 (:508-569).
 
-Out-of-scope collaborators (BERT text encoder, frozen VAE, data loaders,
-TensorBoard) are NOT re-implemented: they are taken from the reference package
-(`src.models`, `src.data`) when it is importable, or injected through
-`components=` (tests, benchmarks with synthetic latents).
+The frozen VAE either side of the path is this package's own (`vae.VAEEncoder` /
+`vae.VAEDecoder`, same kernels).  Out-of-scope collaborators (BERT text encoder,
+data loaders, TensorBoard) are NOT re-implemented: they are taken from the
+reference package (`src.models`, `src.data`) when it is importable, or injected
+through `components=` (tests, benchmarks with synthetic latents).
 
 Bad-batch semantics are the reference's (:353-393): a batch whose text embedding,
 latent, noisy latent, prediction or loss is non-finite is skipped — no optimizer
@@ -334,6 +335,10 @@ class ImprovedDiffusionTrainer:
     def _component(self, name):
         if name in self._components:
             return self._components[name]
+        if name in ("VAEEncoder", "VAEDecoder"):          # the frozen VAE either side of the path runs on the kernels too
+            from . import vae
+            cls = getattr(vae, name)
+            return lambda *a, **k: cls(*a, compute_dtype=self.compute_dtype, **k)
         try:                                   # the reference package, when this class is dropped into its tree
             import importlib
             mod = importlib.import_module({"create_data_loaders": "src.data"}.get(name, "src.models"))
