@@ -152,26 +152,18 @@ __device__ __forceinline__ int conv_out_m(const ConvP& p, int mt) {
 //         gather is a stride-1 gather with 1, 2 or 4 taps (table in ConvP) instead of 9 taps of which 3/4 miss
 // 256 threads = 4 waves (2 along m x 2 along n), two LDS tile buffers: the tile of step kt+1 is requested at the top
 // of step kt (plain __syncthreads at the end of the step).
-// KC = 16-byte chunks per LDS row = per K step (8: 64 bf16 values, 128-byte rows; 4: 32 values, 64-byte rows).
-// A CU moves at most ~64 bytes per clock from L1/L2 into LDS.  A 128x128 tile needs (128+128)*128 B per K step of 2 x 32
-// MFMAs per wave: exactly 64 B/clk at the MFMA peak - the loop is bound by the load pipe AND the matrix pipe at once and
-// reaches two thirds of either.  The 256x128 tile (KC = 4, each wave 128 pixels x 64 channels, 128 accumulator registers)
-// moves (256+128)*64 B per 32 MFMAs per wave: 48 B/clk, 6 instead of 8 LDS-DMA pieces and 12 instead of 16 fragment reads
-// per 32 MFMAs, in the same 48 KB of LDS so that two workgroups still share a CU.
-template <typename T, int BM, int BN, int MODE, int KC = 8>
+template <typename T, int BM, int BN, int MODE>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // the LDS-DMA builtin exists only in the device pass
     constexpr int NT = 256;
     constexpr int CH = Elem<T>::CH;
     constexpr int WM = BM / 2, WN = BN / 2;           // pixels / channels per wave (BN = 160 -> 80 = 5 x 16: bf16 only)
-    constexpr int ROWB = KC * 16;               // bytes per LDS row
-    constexpr int RPP = NT / KC;                // rows per staging pass (KC lanes x 16 B per row)
+    constexpr int RPP = NT / 8;                 // rows per staging pass (8 lanes x 16 B per 128-byte row)
     constexpr int JX = BM / RPP, JW = BN / RPP; // staging passes
-    constexpr int PASS_BYTES = RPP * ROWB;
-    static_assert(KC == 8 || (KC == 4 && sizeof(T) == 2), "KC = 4 is a bf16 form");
+    constexpr int PASS_BYTES = RPP * 128;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    // [buf][W tile BN rows | X tile BM rows], ROWB bytes per row
-    constexpr int BUF_BYTES = (BM + BN) * ROWB;
+    // [buf][W tile BN rows | X tile BM rows], 128 B per row
+    constexpr int BUF_BYTES = (BM + BN) * 128;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave & 1, wm = wave >> 1;
@@ -195,10 +187,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
     // Tiles go global -> LDS by LDS-DMA (buffer_load ... lds): the destination of a wave-instruction is
     // wave-uniform base + lane*16, i.e. 8 consecutive 128-byte rows, so the XOR swizzle is applied on the SOURCE
     // side: the lane sitting at physical chunk (tid & 7) of row sr fetches logical chunk sc.
-    // KC = 4 (64-byte rows): the key is ((row>>3)&1)<<1 - with it the four rows r, r+4, r+8, r+12 that share a bank
-    // quarter sit on four different chunks in every 16-lane group of ds_read_b128 (the groups mix two k-chunks).
-    const int sr = tid / KC;                          // row within a pass
-    const int sc = (tid % KC) ^ (KC == 8 ? ((sr >> 1) & 7) : (((sr >> 3) & 1) << 1));   // logical chunk this lane fetches (pass-invariant key)
+    const int sr = tid >> 3;                          // row within a 32-row pass
+    const int sc = (tid & 7) ^ ((sr >> 1) & 7);       // logical chunk this lane fetches ((row>>1)&7 is pass-invariant)
 
     // Branch-free gathers: raw buffer loads return 0 for an out-of-range offset, so padding taps,
     // rows beyond M / N and the K tail cost no control flow (and no per-load s_waitcnt).
@@ -248,9 +238,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
         // shifted by a row / a column, back to back, so 8 of the 9 gathers hit L2 (tap-outermost spreads them a whole
         // channel sweep apart and every one misses): +2..9 % on the 3x3 layers.  The weight K offset follows the walk.
         const uint32_t kbytes = MODE == 3 ? (uint32_t)(p.tap_wi[t_kh] * p.cpt + t_c0) * 16u
-                              : (MODE == 2 ? (uint32_t)kt * (uint32_t)ROWB : (uint32_t)((t_kh * p.ks + t_kw) * p.cpt + t_c0) * 16u);
+                              : (MODE == 2 ? (uint32_t)kt * 128u : (uint32_t)((t_kh * p.ks + t_kw) * p.cpt + t_c0) * 16u);
         const uint32_t wdst = lds_wave + (uint32_t)buf * BUF_BYTES;
-        const uint32_t xdst = wdst + BN * ROWB;
+        const uint32_t xdst = wdst + BN * 128;
 #pragma unroll
         for (int j = 0; j < JW; ++j)
             lds_dma16(wrs, wdst + j * PASS_BYTES, w_off[j] + kbytes);
@@ -265,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
                 off = ok ? off : OOB;
                 lds_dma16(xrs, xdst + j * PASS_BYTES, off);
             }
-            if (++t_kh == p.ntap) { t_kh = 0; t_c0 += KC; }      // taps innermost, as in modes 0/1
+            if (++t_kh == p.ntap) { t_kh = 0; t_c0 += 8; }       // taps innermost, as in modes 0/1
         } else if (MODE != 2) {
             const int sgn = MODE == 0 ? 1 : -1;
             const int delta = (sgn * (t_kh * p.Wi + t_kw) * (int)p.ldx + t_c0 * CH) * ESZ;      // wave-uniform
@@ -277,9 +267,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
                 off = ok ? off : OOB;
                 lds_dma16(xrs, xdst + j * PASS_BYTES, off);
             }
-            if (++t_kw == p.ks) { t_kw = 0; if (++t_kh == p.ks) { t_kh = 0; t_c0 += KC; } }
+            if (++t_kw == p.ks) { t_kw = 0; if (++t_kh == p.ks) { t_kh = 0; t_c0 += 8; } }
         } else {
-            const int qi = kt * KC + sc;
+            const int qi = kt * 8 + sc;
             const int tap = qi / p.cpt, cc = qi - tap * p.cpt;
             const bool tap_ok = tap < p.taps;
             const int kh = tap / p.ks, kw = tap - kh * p.ks;
@@ -320,20 +310,19 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
     const int l16 = lane & 15, kq = lane >> 4;            // 16x16x32 fragment coordinates (bf16 path)
     // fragment row bases (bytes) and chunk swizzle key; tile rows step by 16 / 32, which leaves (row>>1)&7 unchanged
     const int frow = FT16 ? l16 : fr;
-    static_assert((WN / 2) % 8 == 0 && (WM / 2) % 8 == 0, "wave row bases must keep the swizzle key");
-    const int rd_w = (wn * WN + frow) * ROWB, rd_x = BN * ROWB + (wm * WM + frow) * ROWB;
-    const int swz = KC == 8 ? ((frow >> 1) & 7) : (((frow >> 3) & 1) << 1);
-    constexpr int FSTEP = (FT16 ? 16 : 32) * ROWB;        // byte step between fragment tiles
-    constexpr int NS2 = KC / 4;                           // 32-deep MFMA sub-steps per K step (bf16)
+    static_assert((WN / 2) % 8 == 0 && (WM / 2) % 8 == 0, "wave row bases must keep the (row>>1)&7 swizzle key");
+    const int rd_w = (wn * WN + frow) * 128, rd_x = BN * 128 + (wm * WM + frow) * 128;
+    const int swz = (frow >> 1) & 7;
+    constexpr int FSTEP = (FT16 ? 16 : 32) * 128;         // byte step between fragment tiles
 
     auto compute = [&](int buf) {
         const char* tb = smem + buf * BUF_BYTES;
         if constexpr (FT16) {
             // all 2 x (NA + NB) fragment reads of the K tile are issued up front (64 VGPRs); the MFMAs start as the
             // first ones land and the rest of the LDS latency hides under the 2 x NA x NB MFMA stream
-            uint4 wf[NS2][NA], xf[NS2][NB];
+            uint4 wf[2][NA], xf[2][NB];
 #pragma unroll
-            for (int s2 = 0; s2 < NS2; ++s2) {
+            for (int s2 = 0; s2 < 2; ++s2) {
                 const int co = ((4 * s2 + kq) ^ swz) << 4;
 #pragma unroll
                 for (int i = 0; i < NA; ++i) wf[s2][i] = *reinterpret_cast<const uint4*>(tb + rd_w + i * FSTEP + co);
@@ -342,7 +331,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
             }
             __builtin_amdgcn_sched_barrier(0);      // keep the reads ABOVE the MFMA stream (hipcc otherwise sinks them)
 #pragma unroll
-            for (int s2 = 0; s2 < NS2; ++s2)
+            for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                 for (int i = 0; i < NA; ++i)
 #pragma unroll
@@ -388,14 +377,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     int rows[FT16 ? NB : 1], smp[FT16 ? NB : 1];
     f32x4 bias4[FT16 ? NA : 1];
-    // (a wave of the 256-row tile owns 128 pixels: prefetching their residual would cost 64 registers - it is loaded in
-    //  the epilogue there, per 64-row block; those are the long-K 3x3 layers, where the epilogue is a small share)
-    constexpr bool BIGW = WM > 64;
-    bf16x4 res_raw[FT16 && !BIGW ? NA : 1][FT16 && !BIGW ? NB : 1];
+    bf16x4 res_raw[FT16 ? NA : 1][FT16 ? NB : 1];
     // LDS-staged epilogue: the residual / saved derivative is fetched ROW-major instead (16 bytes per lane, whole 128-byte
     // lines per instruction) and turned into the accumulator layout through the wave's LDS region - exact, it is bf16
     constexpr int E_CPRW = FT16 ? WN / 8 : 1, E_NCH = FT16 ? WM * E_CPRW : 1, E_NIT = (E_NCH + 63) / 64;
-    uint4 res_row[FT16 && !BIGW ? E_NIT : 1];
+    uint4 res_row[FT16 ? E_NIT : 1];
     if constexpr (FT16) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) {
@@ -407,18 +393,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
             const int mt_ = m0 + wm * WM + j * 16 + l16;
             rows[j] = -1; smp[j] = 0;
             if (mt_ < p.M) conv_out_row<MODE>(p, mt_, rows[j], smp[j]);
-            if constexpr (!BIGW) {
-                if (resg && !p.epi_lds) {
+            if (resg && !p.epi_lds) {
 #pragma unroll
-                    for (int i = 0; i < NA; ++i) {
-                        const int n = n0 + wn * WN + i * 16 + 4 * kq;
-                        if (rows[j] >= 0 && n < p.N) res_raw[i][j] = *reinterpret_cast<const bf16x4*>(resg + (int64_t)rows[j] * ldaux + n);
-                    }
+                for (int i = 0; i < NA; ++i) {
+                    const int n = n0 + wn * WN + i * 16 + 4 * kq;
+                    if (rows[j] >= 0 && n < p.N) res_raw[i][j] = *reinterpret_cast<const bf16x4*>(resg + (int64_t)rows[j] * ldaux + n);
                 }
             }
         }
     }
-    if constexpr (FT16 && !BIGW) {
+    if constexpr (FT16) {
         if (resg && p.epi_lds) {
 #pragma unroll
             for (int it = 0; it < E_NIT; ++it) {
@@ -454,74 +438,56 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
             // rounding to bf16, bit-identical to the direct form).  `preact` takes the same route in a first pass.
             constexpr int CPRW = WN / 8;                       // 16-byte chunks per sub-tile row
             constexpr int PITCH = WN * 2 + 16;                 // bytes; (PITCH/4) mod 64 = 36 / 20 / 44: distinct banks for 16 rows
-            constexpr int RBL = BIGW ? 64 : WM;                // rows staged at a time (the wave's region must fit the tile LDS)
-            constexpr int NBLK = WM / RBL, JB = RBL / 16;
-            constexpr int NCH = RBL * CPRW;                    // chunks per staged block
+            constexpr int NCH = WM * CPRW;                     // chunks per sub-tile
             constexpr int NIT = (NCH + 63) / 64;
-            char* reg = smem + wave * (RBL * PITCH);
-            const uint4 z4 = {0u, 0u, 0u, 0u};
+            char* reg = smem + wave * (WM * PITCH);
             auto stage_and_flush = [&](auto pass_c) {
                 constexpr int PASS = decltype(pass_c)::value;      // 0: the `preact` tensor, 1: y
-#pragma unroll
-                for (int blk = 0; blk < NBLK; ++blk) {
-                    if (resg) {                                    // residual rows -> LDS (read back per accumulator cell below)
-                        uint4 rr[NIT];
-#pragma unroll
-                        for (int it = 0; it < NIT; ++it) {
-                            if constexpr (BIGW) {
-                                const int idx = it * 64 + lane;
-                                const int row = idx / CPRW, chk = idx - row * CPRW;
-                                const int mt_ = m0 + wm * WM + blk * RBL + row, n = n0 + wn * WN + chk * 8;
-                                rr[it] = (idx < NCH && mt_ < p.M && n < p.N)
-                                             ? *reinterpret_cast<const uint4*>(resg + (int64_t)conv_out_m<MODE>(p, mt_) * ldaux + n) : z4;
-                            } else rr[it] = res_row[it];
-                        }
-#pragma unroll
-                        for (int it = 0; it < NIT; ++it) {
-                            const int idx = it * 64 + lane;
-                            const int row = idx / CPRW, chk = idx - row * CPRW;
-                            if (idx < NCH) *reinterpret_cast<uint4*>(reg + row * PITCH + chk * 16) = rr[it];
-                        }
-                    }
-#pragma unroll
-                    for (int jj = 0; jj < JB; ++jj) {
-                        const int j = blk * JB + jj;
-                        f32x4 ra4[NA];
-#pragma unroll
-                        for (int i = 0; i < NA; ++i) {
-                            const int n = n0 + wn * WN + i * 16 + 4 * kq;
-                            ra4[i] = (rag && rows[j] >= 0 && n < p.N) ? load4<T>(rag + (int64_t)smp[j] * p.ldra + n) : zero4;
-                        }
-#pragma unroll
-                        for (int i = 0; i < NA; ++i) {
-                            const int n = n0 + wn * WN + i * 16 + 4 * kq;
-                            f32x4 v = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                            f32x4 r4 = zero4, pre;
-                            char* cell = reg + (jj * 16 + l16) * PITCH + (i * 16 + 4 * kq) * 2;    // this lane's 4 channels of its pixel
-                            if (resg) {
-                                const bf16x4 rr = *reinterpret_cast<const bf16x4*>(cell);
-                                r4[0] = (float)rr[0]; r4[1] = (float)rr[1]; r4[2] = (float)rr[2]; r4[3] = (float)rr[3];
-                            }
-                            conv_value<T>(p, rows[j], n, v, pre, bias4[i], ra4[i], r4);
-                            const f32x4 o = PASS == 0 ? pre : v;
-                            bf16x4 ob = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
-                            *reinterpret_cast<bf16x4*>(cell) = ob;
-                        }
-                        __builtin_amdgcn_sched_barrier(0);          // one pixel row of tiles at a time (register pressure)
-                    }
-                    T* dst = reinterpret_cast<T*>(PASS == 0 ? p.preact : p.y);
-                    const int64_t ldd = PASS == 0 ? p.ldpre : p.ldy;
+                if (resg) {                                        // residual rows -> LDS (read back per accumulator cell below)
 #pragma unroll
                     for (int it = 0; it < NIT; ++it) {
                         const int idx = it * 64 + lane;
                         const int row = idx / CPRW, chk = idx - row * CPRW;
-                        const int mt_ = m0 + wm * WM + blk * RBL + row, n = n0 + wn * WN + chk * 8;
-                        if (idx < NCH && mt_ < p.M && n < p.N) {
-                            const uint4 val = *reinterpret_cast<const uint4*>(reg + row * PITCH + chk * 16);
-                            *reinterpret_cast<uint4*>(dst + (int64_t)conv_out_m<MODE>(p, mt_) * ldd + n) = val;
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
+                        if (idx < NCH) *reinterpret_cast<uint4*>(reg + row * PITCH + chk * 16) = res_row[it];
                     }
+                }
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    f32x4 ra4[NA];
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) {
+                        const int n = n0 + wn * WN + i * 16 + 4 * kq;
+                        ra4[i] = (rag && rows[j] >= 0 && n < p.N) ? load4<T>(rag + (int64_t)smp[j] * p.ldra + n) : zero4;
+                    }
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) {
+                        const int n = n0 + wn * WN + i * 16 + 4 * kq;
+                        f32x4 v = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                        f32x4 r4 = zero4, pre;
+                        char* cell = reg + (j * 16 + l16) * PITCH + (i * 16 + 4 * kq) * 2;     // this lane's 4 channels of pixel j*16+l16
+                        if (resg) {
+                            const bf16x4 rr = *reinterpret_cast<const bf16x4*>(cell);
+                            r4[0] = (float)rr[0]; r4[1] = (float)rr[1]; r4[2] = (float)rr[2]; r4[3] = (float)rr[3];
+                        }
+                        conv_value<T>(p, rows[j], n, v, pre, bias4[i], ra4[i], r4);
+                        const f32x4 o = PASS == 0 ? pre : v;
+                        bf16x4 ob = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
+                        *reinterpret_cast<bf16x4*>(cell) = ob;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);          // one pixel row of tiles at a time (register pressure)
+                }
+                T* dst = reinterpret_cast<T*>(PASS == 0 ? p.preact : p.y);
+                const int64_t ldd = PASS == 0 ? p.ldpre : p.ldy;
+#pragma unroll
+                for (int it = 0; it < NIT; ++it) {
+                    const int idx = it * 64 + lane;
+                    const int row = idx / CPRW, chk = idx - row * CPRW;
+                    const int mt_ = m0 + wm * WM + row, n = n0 + wn * WN + chk * 8;
+                    if (idx < NCH && mt_ < p.M && n < p.N) {
+                        const uint4 val = *reinterpret_cast<const uint4*>(reg + row * PITCH + chk * 16);
+                        *reinterpret_cast<uint4*>(dst + (int64_t)conv_out_m<MODE>(p, mt_) * ldd + n) = val;
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             };
             if (p.preact) stage_and_flush(std::integral_constant<int, 0>{});
@@ -543,8 +509,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
                 if (n >= p.N) continue;
                 f32x4 v = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                 f32x4 r4 = zero4;
-                if constexpr (BIGW) { if (resg) r4 = load4<T>(resg + (int64_t)rows[j] * ldaux + n); }
-                else if (resg) { r4[0] = (float)res_raw[i][j][0]; r4[1] = (float)res_raw[i][j][1]; r4[2] = (float)res_raw[i][j][2]; r4[3] = (float)res_raw[i][j][3]; }
+                if (resg) { r4[0] = (float)res_raw[i][j][0]; r4[1] = (float)res_raw[i][j][1]; r4[2] = (float)res_raw[i][j][2]; r4[3] = (float)res_raw[i][j][3]; }
                 conv_emit<T>(p, rows[j], n, v, bias4[i], ra4[i], r4);
             }
         }
@@ -601,24 +566,6 @@ static int launch_conv(const ConvP& p, hipStream_t stream) {
     return PSG_OK;
 }
 
-// the 256 x 128 tile with 64-byte K steps (KC = 4): bf16, fast gathers (modes 0 / 1) only
-static int launch_conv_big(const ConvP& p, hipStream_t stream) {
-    constexpr int BM = 256, BN = 128, KC = 4;
-    const size_t lds = (size_t)2 * (BM + BN) * KC * 16;
-    ConvP q = p;
-    q.mtiles = (p.M + BM - 1) / BM;
-    q.ntiles = (p.N + BN - 1) / BN;
-    q.KT = p.KT * 2;                            // K steps of 4 chunks instead of 8 (Kpad is a multiple of 64 values)
-    q.tpt = p.cpt / KC;
-    const int grid = q.mtiles * q.ntiles;
-    ProfScope prof(p.transposed ? PROF_CONV_DGRAD : PROF_CONV_FWD, 2.0 * (double)p.M * (double)p.N * (double)p.taps * (double)p.Cin, stream);
-    if (!p.transposed) hipLaunchKernelGGL((conv_gemm_kernel<bf16_t, BM, BN, 0, KC>), dim3(grid), dim3(256), lds, stream, q);
-    else hipLaunchKernelGGL((conv_gemm_kernel<bf16_t, BM, BN, 1, KC>), dim3(grid), dim3(256), lds, stream, q);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return hip_fail(e, "conv_gemm(256x128) launch");
-    return PSG_OK;
-}
-
 template <typename T, int BM, int BN>
 static int set_conv_attrs() {
     const int lds = 2 * (BM + BN) * 128;
@@ -637,31 +584,21 @@ static int choose_and_launch(const ConvP& p, int dtype, hipStream_t s) {
     {
         static int force = -2;                             // PSG_CONV_TILE=0..3 pins a candidate (kernel A/B runs)
         if (force == -2) { const char* e = getenv("PSG_CONV_TILE"); force = e ? atoi(e) : -1; }
-        const int cand[6][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 160}, {64, 160}, {256, 128}};
-        double eff[6] = {1.0, 0.78, 0.55, 1.0, 0.70, 1.12};   // measured relative MFMA efficiency of the tile shapes
-        {
-            static double e5 = -1.0;                       // PSG_CONV_BIG_EFF overrides the 256x128 estimate (0 = never use it)
-            if (e5 < 0) { const char* e = getenv("PSG_CONV_BIG_EFF"); e5 = e ? atof(e) : 1.12; }
-            eff[5] = e5;
-        }
-        // 256x128: bf16 fast gathers (modes 0 / 1), whole 128-channel tiles, LDS-staged epilogue
-        const bool big_ok = dtype == PSG_BF16 && p.fast && p.ntap == 0 && (!p.transposed || p.stride == 1) && p.N % 128 == 0 && p.epi_lds &&
-                            p.cpt % 4 == 0;
-        if (!big_ok) eff[5] = 0.0;
+        const int cand[5][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 160}, {64, 160}};
+        double eff[5] = {1.0, 0.78, 0.55, 1.0, 0.70};      // measured relative MFMA efficiency of the tile shapes
         if (p.KT <= 10) eff[1] = 1.1;                      // K <= 640: 3 resident 128x64 workgroups hide the short K loop's ends
         if (dtype != PSG_BF16 || p.ntap > 0) eff[3] = eff[4] = 0.0;   // 160 = 2 x 5 x 16: only the 16x16x32 bf16 tiles divide it
         const double slots = 512.0;                        // resident workgroups on the chip (2 per CU)
         double best = -1.0;
-        for (int c = 0; c < 6; ++c) {
+        for (int c = 0; c < 5; ++c) {
             const double tiles = (double)((M + cand[c][0] - 1) / cand[c][0]) * (double)((p.N + cand[c][1] - 1) / cand[c][1]);
             const double useful = (double)M * p.N / (tiles * cand[c][0] * cand[c][1]);
             const double waves = ceil(tiles / slots);
             double score = useful * (tiles / (waves * slots)) * eff[c];
-            if (force >= 0 && eff[force] > 0.0) score = (c == force) ? 1.0 : 0.0;     // (a pinned tile that cannot run this launch is ignored)
+            if (force >= 0) score = (c == force) ? 1.0 : 0.0;
             if (score > best) { best = score; BM = cand[c][0]; BN = cand[c][1]; }
         }
     }
-    if (BM == 256) return launch_conv_big(p, s);
     if (BN == 160 && BM == 64) return launch_conv<bf16_t, 64, 160>(p, s);
     if (BN == 160) return launch_conv<bf16_t, 128, 160>(p, s);
     if (dtype == PSG_F32) {
@@ -690,8 +627,6 @@ int psg_conv_init_attrs(void) {
     if ((rc = set_conv_attrs<bf16_t, 64, 64>())) return rc;
     if ((rc = set_conv_attrs<bf16_t, 128, 160>())) return rc;
     if ((rc = set_conv_attrs<bf16_t, 64, 160>())) return rc;
-    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<bf16_t, 256, 128, 0, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 384 * 64));
-    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<bf16_t, 256, 128, 1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 384 * 64));
     return PSG_OK;
 }
 
