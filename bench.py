@@ -181,8 +181,15 @@ def launch_ranks(n, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         out = subprocess.PIPE if r == 0 else subprocess.DEVNULL
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out))
-    line, _ = procs[0].communicate()
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    try:
+        line, _ = procs[0].communicate(timeout=float(os.environ.get("PSG_BENCH_TIMEOUT", "1700")))
+        codes = [procs[0].returncode] + [p.wait(timeout=120) for p in procs[1:]]
+    except subprocess.TimeoutExpired:           # a rank hung (e.g. in the rendezvous): stop exactly the processes started here
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        sys.stderr.write("bench.py: a rank did not finish in time; workers killed\n")
+        return 124
     sys.stdout.write(line.decode() if line else "")
     sys.stdout.flush()
     return max(abs(c) for c in codes)

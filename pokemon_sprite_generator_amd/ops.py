@@ -464,6 +464,10 @@ def linear(x, weight, bias=None, residual=None, act=ACT_NONE, alpha=1.0, drop_p=
     return _ConvFn.apply(x, weight, bias, None, residual, 1, act, alpha, drop_p, seed)
 
 
+_FFN_SAVE_DACT = os.environ.get("PSG_FFN_SAVE_DACT", "1") != "0"     # 0: save u, re-evaluate gelu'(u) and the mask in backward (A/B)
+_GN_SPLIT = os.environ.get("PSG_GN_SPLIT", "1") != "0"               # 0: plain GroupNorm node, autograd adds the bypass gradient (A/B)
+
+
 class _FFNFn(torch.autograd.Function):
     """y = x + alpha * drop2(W2 . drop1(gelu(W1 x + b1)) + b2)   - the FFN of CrossAttentionBlock (unet.py:176-187, 250).
 
@@ -488,7 +492,7 @@ class _FFNFn(torch.autograd.Function):
         g1 = (M, 1, 1, 1, 1, 1, 1, 0)
         # `u` receives gelu'(W1 x + b1) * mask1 / (1 - p), not the pre-activation: backward multiplies by it
         _conv_launch(lib, dtype, xr, ldx, wf1, 0, hmid, Hd, g1, C, Hd, bias=b1, preact=u, act=ACT_GELU, drop_p=drop_p, seed=seed1,
-                     flags=_lib.CONV_SAVE_DACT if u is not None else 0)
+                     flags=_lib.CONV_SAVE_DACT if (u is not None and _FFN_SAVE_DACT) else 0)
         _conv_launch(lib, dtype, hmid, Hd, wf2, 0, y, C, g1, Hd, C, bias=b2, residual=xr, ld_res=ldx, alpha=alpha, drop_p=drop_p, seed=seed2)
         ctx.save_for_backward(xr, u, hmid, w1, w2)
         ctx.params = (w1, b1, w2, b2)
@@ -514,7 +518,10 @@ class _FFNFn(torch.autograd.Function):
                                    dtype_code(dtype), stream_ptr()), "psg_epilogue_bwd")
         # d/du of the first Linear's pre-activation: dgrad of Linear 2 with the backward-form epilogue
         gu = torch.empty((M, Hd), dtype=dtype, device=dy.device)
-        _conv_launch(lib, dtype, g2, C, wd2, 0, gu, Hd, geo, C, Hd, transposed=True, dact_u=u, ld_dact=Hd, flags=_lib.CONV_DACT_MUL)
+        if _FFN_SAVE_DACT:
+            _conv_launch(lib, dtype, g2, C, wd2, 0, gu, Hd, geo, C, Hd, transposed=True, dact_u=u, ld_dact=Hd, flags=_lib.CONV_DACT_MUL)
+        else:
+            _conv_launch(lib, dtype, g2, C, wd2, 0, gu, Hd, geo, C, Hd, transposed=True, dact_u=u, ld_dact=Hd, act=ACT_GELU, drop_p=drop_p, seed=seed1)
 
         def wgrad(xin, ldxin, g, ldg, wp, bp, cin, cout):
             wo, wacc, we = _param_out(wp)
@@ -680,7 +687,7 @@ def group_norm(x, gamma, beta, groups, eps=1e-5, silu=False):
 def group_norm_split(x, gamma, beta, groups, eps=1e-5, silu=False):
     """(GroupNorm(x), x): use the second result wherever x itself is consumed next to the norm (skip / residual
     paths), so the two gradients meet inside the GroupNorm-backward kernel (see _GroupNormFn)."""
-    if not (torch.is_grad_enabled() and x.requires_grad):
+    if not (_GN_SPLIT and torch.is_grad_enabled() and x.requires_grad):
         return _GroupNormFn.apply(x, gamma, beta, groups, eps, silu), x
     return _GroupNormFn.apply(x, gamma, beta, groups, eps, silu, True)
 
