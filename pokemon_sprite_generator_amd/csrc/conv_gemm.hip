@@ -599,6 +599,12 @@ static int choose_and_launch(const ConvP& p, int dtype, hipStream_t s) {
             if (score > best) { best = score; BM = cand[c][0]; BN = cand[c][1]; }
         }
     }
+    {
+        static int dbg = -1;                               // PSG_CONV_DEBUG=1: print the tile chosen for every launch
+        if (dbg < 0) { const char* e = getenv("PSG_CONV_DEBUG"); dbg = e ? atoi(e) : 0; }
+        if (dbg) fprintf(stderr, "psg conv: M=%d N=%d Cin=%d ks=%d tr=%d fast=%d epi_lds=%d -> tile %dx%d\n", p.M, p.N, p.Cin, p.ks, p.transposed,
+                         p.fast, p.epi_lds, BM, BN);
+    }
     if (BN == 160 && BM == 64) return launch_conv<bf16_t, 64, 160>(p, s);
     if (BN == 160) return launch_conv<bf16_t, 128, 160>(p, s);
     if (dtype == PSG_F32) {
