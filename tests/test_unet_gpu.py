@@ -206,8 +206,9 @@ def test_train_step_golden_bf16(psg, golden, full_unets):
     """The BENCHMARKED arithmetic (bf16 MFMA, fp32 accumulate / master / gradients) against the same reference fixture as
     the fp32 leg above: eps-hat, loss, the global gradient norm, all 478 per-parameter gradient norms and the sampled
     gradient slices.  Bars (bf16 has 8 significant bits; stated, not hidden): eps-hat MSE < 1e-3 and rel-L2 < 3e-2; loss
-    rel < 2e-2; global |g| rel < 3e-2; the VECTOR of per-parameter norms rel-L2 < 3e-2 and every single one within 10 %;
-    every sampled slice rel-L2 < 6e-2 (per-element noise of a bf16 chain ~ 1-3 %)."""
+    rel < 2e-2; global |g| rel < 1e-2; the VECTOR of per-parameter norms rel-L2 < 1e-2 and every single one within 2 %;
+    every sampled slice rel-L2 < 4e-2 (per-element noise of a bf16 chain ~ 1-3 %).  Measured on MI355X: MSE 2.8e-5,
+    rel-L2 8.1e-3, loss 2.1e-4, |g| 2.3e-3, norm vector 2.1e-3, worst single norm 4.0e-3, worst slice 2.1e-2."""
     g = golden("unet_full.npz")
     name, mode, b, ts, heads = cases.TRAIN_CASE
     u, _ = full_unets(mode, heads)
@@ -245,9 +246,9 @@ def test_train_step_golden_bf16(psg, golden, full_unets):
         print(f"bf16 train step vs reference fixture: eps MSE {mse:.2e} rel-L2 {r_eps:.2e}; loss rel {l_rel:.2e}; |g| rel {gn_rel:.2e}; "
               f"per-param norm vector rel-L2 {vec_rel:.2e}, worst single {each.max():.2e} (#{each.argmax()}); worst slice rel-L2 {worst_slice:.2e}")
         assert mse < 1e-3 and r_eps < 3e-2
-        assert l_rel < 2e-2 and gn_rel < 3e-2
-        assert vec_rel < 3e-2 and each.max() < 0.10, f"per-parameter grad norms: vector {vec_rel:.2e}, worst {each.max():.2e} at #{each.argmax()}"
-        assert worst_slice < 6e-2
+        assert l_rel < 2e-2 and gn_rel < 1e-2
+        assert vec_rel < 1e-2 and each.max() < 0.02, f"per-parameter grad norms: vector {vec_rel:.2e}, worst {each.max():.2e} at #{each.argmax()}"
+        assert worst_slice < 4e-2
         assert int(st.flag.item()) == 0
     finally:
         u.set_compute_dtype(torch.float32)
