@@ -274,9 +274,10 @@ int psg_dropout_apply(const void* x, int64_t ldx, void* y, int64_t ldy, int64_t 
 int psg_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                  void* o, int64_t ldo, float* lse, int B, int heads, int L, int S, int d, float scale,
                  float drop_p, uint64_t seed, int dtype, psg_stream_t stream);
-/* Diagnostic: launches of psg_attn_fwd / psg_attn_bwd served so far by the MFMA kernels (bf16, head_dim 16 / 32 / 80 /
- * 160 / 320, 16-byte aligned rows) and by the VALU kernels (fp32, other shapes).  Both paths draw the same dropout mask. */
-int psg_attn_path_counts(int64_t* mfma, int64_t* valu);
+/* Diagnostic: launches of psg_attn_fwd / psg_attn_bwd served so far by the bf16 MFMA kernels (head_dim 16 / 32 / 64 / 80 /
+ * 160 / 320, 16-byte aligned rows), by the VALU kernels (other shapes) and by the exact-fp32 MFMA kernels (fp32, head_dim
+ * 16 / 32 / 64 / 80 / 160 while K/V - and Q/dO for backward - fit LDS).  All paths draw the same dropout mask. */
+int psg_attn_path_counts(int64_t* mfma, int64_t* valu, int64_t* mfma_f32);
 /* delta: fp32 [B, heads, L] scratch.  dq/dk/dv have the strides of q/k/v. */
 int psg_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                  const void* o, int64_t ldo, const void* dout, int64_t lddo, const float* lse,

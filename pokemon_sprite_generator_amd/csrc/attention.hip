@@ -337,6 +337,32 @@ int attn_mfma_init_attrs();
 int attn_mfma_fwd(const AttnMP& p, hipStream_t s);
 int attn_mfma_bwd(const AttnMP& p, hipStream_t s);
 
+// attention_f32.hip (exact-fp32 matrix-core path)
+struct AttnFP {
+    const float *q, *k, *v, *o, *dout;
+    float *out, *dq, *dk, *dv;
+    float* lse; float* delta;
+    int64_t ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;
+    int B, H, L, S, d;
+    float scale;
+    uint32_t drop_thresh; float drop_scale; uint64_t seed;
+};
+int attn_f32_applicable(int L, int S, int d, int dtype, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo);
+int attn_f32_init_attrs();
+int attn_f32_fwd(const AttnFP& p, hipStream_t s);
+int attn_f32_bwd(const AttnFP& p, hipStream_t s);
+
+static AttnFP to_f32(const AttnP& a) {
+    AttnFP m;
+    m.q = (const float*)a.q; m.k = (const float*)a.k; m.v = (const float*)a.v; m.o = (const float*)a.o; m.dout = (const float*)a.dout;
+    m.out = (float*)a.out; m.dq = (float*)a.dq; m.dk = (float*)a.dk; m.dv = (float*)a.dv;
+    m.lse = a.lse; m.delta = a.delta;
+    m.ldq = a.ldq; m.ldk = a.ldk; m.ldv = a.ldv; m.ldo = a.ldo; m.lddo = a.lddo; m.lddq = a.lddq; m.lddk = a.lddk; m.lddv = a.lddv;
+    m.B = a.B; m.H = a.H; m.L = a.L; m.S = a.S; m.d = a.d; m.scale = a.scale;
+    m.drop_thresh = a.drop_thresh; m.drop_scale = a.drop_scale; m.seed = a.seed;
+    return m;
+}
+
 static AttnMP to_mfma(const AttnP& a) {
     AttnMP m;
     m.q = (const bf16_t*)a.q; m.k = (const bf16_t*)a.k; m.v = (const bf16_t*)a.v; m.o = (const bf16_t*)a.o; m.dout = (const bf16_t*)a.dout;
@@ -355,6 +381,7 @@ extern "C" {
 
 int psg_attn_init_attrs(void) {
     { int rc = attn_mfma_init_attrs(); if (rc) return rc; }
+    { int rc = attn_f32_init_attrs(); if (rc) return rc; }
     const int big = 150 * 1024;
 #define SET_LDS(K) PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&K), hipFuncAttributeMaxDynamicSharedMemorySize, big))
     SET_LDS(attn_fwd_kernel<float>); SET_LDS(attn_fwd_kernel<bf16_t>);
@@ -364,10 +391,16 @@ int psg_attn_init_attrs(void) {
     return PSG_OK;
 }
 
-static int64_t g_attn_paths[2] = {0, 0};            // launches taken by the MFMA / the VALU kernels (tests assert the path)
-int psg_attn_path_counts(int64_t* mfma, int64_t* valu) {
+static int64_t g_attn_paths[3] = {0, 0, 0};         // launches taken by the bf16 MFMA / the VALU / the fp32 MFMA kernels
+static int f32_mfma_on() {
+    static int on = -1;                              // PSG_ATTN_F32_MFMA=0: the strict path runs the VALU kernels (A/B)
+    if (on < 0) { const char* e = getenv("PSG_ATTN_F32_MFMA"); on = (e && atoi(e) == 0) ? 0 : 1; }
+    return on;
+}
+int psg_attn_path_counts(int64_t* mfma, int64_t* valu, int64_t* mfma_f32) {
     if (mfma) *mfma = g_attn_paths[0];
     if (valu) *valu = g_attn_paths[1];
+    if (mfma_f32) *mfma_f32 = g_attn_paths[2];
     return PSG_OK;
 }
 
@@ -389,6 +422,10 @@ int psg_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const v
     if (attn_mfma_applicable(L, S, d, dtype, ldq, ldk, ldv, ldo) && aligned16(q) && aligned16(k) && aligned16(v) && aligned8(o)) {
         ++g_attn_paths[0];
         return attn_mfma_fwd(to_mfma(p), (hipStream_t)stream);
+    }
+    if (f32_mfma_on() && attn_f32_applicable(L, S, d, dtype, ldq, ldk, ldv, ldo) && aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o)) {
+        ++g_attn_paths[2];
+        return attn_f32_fwd(to_f32(p), (hipStream_t)stream);
     }
     ++g_attn_paths[1];
     if (dtype == PSG_F32) hipLaunchKernelGGL(attn_fwd_kernel<float>, grid, dim3(256), lds, (hipStream_t)stream, p);
@@ -424,6 +461,11 @@ int psg_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const v
         aligned16(v) && aligned16(o) && aligned16(dout) && aligned8(dq) && aligned8(dk) && aligned8(dv)) {
         ++g_attn_paths[0];
         return attn_mfma_bwd(to_mfma(p), s);       // (delta is produced inside the dQ kernel)
+    }
+    if (f32_mfma_on() && attn_f32_applicable(L, S, d, dtype, ldq, ldk, ldv, ldo) && ((lddo | lddq | lddk | lddv) & 3) == 0 && aligned16(q) &&
+        aligned16(k) && aligned16(v) && aligned16(o) && aligned16(dout) && aligned16(dq) && aligned16(dk) && aligned16(dv)) {
+        ++g_attn_paths[2];
+        return attn_f32_bwd(to_f32(p), s);          // (delta is produced inside the dQ kernel)
     }
     ++g_attn_paths[1];
     if (dtype == PSG_F32) {

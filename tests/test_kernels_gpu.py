@@ -397,6 +397,7 @@ ATTN_CASES = [  # B, heads, L, S, d, self
     (2, 8, 196, 32, 80, False), (1, 4, 49, 20, 320, False), (1, 8, 49, 32, 160, False),
     # the reference CLI's real head count: 4 heads at 1280 channels -> head_dim 320 (improved_diffusion_trainer.py:215)
     (2, 4, 49, 49, 320, True), (2, 4, 16, 16, 320, True), (2, 4, 16, 32, 320, False), (1, 4, 49, 32, 320, False),
+    (2, 8, 40, 20, 64, False),                       # head_dim 64: the VAE decoder's first cross-attention (512 channels, 8 heads)
 ]
 
 
@@ -444,24 +445,26 @@ def test_attention(psg, dtype, B, heads, L, S, d, self_mode):
 
 def _attn_paths():
     from pokemon_sprite_generator_amd import _lib
-    a, b = C.c_int64(0), C.c_int64(0)
-    _lib.check(_lib.init(0).psg_attn_path_counts(C.byref(a), C.byref(b)), "psg_attn_path_counts")
-    return a.value, b.value
+    a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    _lib.check(_lib.init(0).psg_attn_path_counts(C.byref(a), C.byref(b), C.byref(c)), "psg_attn_path_counts")
+    return a.value, b.value, c.value
 
 
 @pytest.mark.parametrize("d", [16, 32, 80, 160, 320])
 def test_attention_bf16_takes_the_mfma_kernels(psg, d):
     """bf16 attention at every head_dim the U-Net produces (8 heads: 80 / 160; the CLI's 4 heads: 160 / 320) must run on
-    the matrix cores, forward and backward; fp32 runs the VALU kernels."""
+    the matrix cores, forward and backward; so must fp32 (exact-fp32 MFMA) up to head_dim 160 - head_dim 320 in fp32 does
+    not fit K and V in LDS at 7x7 and runs the VALU kernels."""
     from pokemon_sprite_generator_amd import ops
     heads, L = 4, 49
     qkv = h((2, L, 3 * heads * d), f"path{d}", 1.0)
-    for dtype, col in ((torch.bfloat16, 0), (torch.float32, 1)):
+    for dtype, col in ((torch.bfloat16, 0), (torch.float32, 2 if d <= 160 else 1)):
         before = _attn_paths()
         x = qkv.to(dtype).to(DEV).requires_grad_(True)
         ops.attention_self(x, heads).sum().backward()
         after = _attn_paths()
-        assert after[col] - before[col] == 2 and after[1 - col] == before[1 - col], (dtype, before, after)
+        for c in range(3):
+            assert after[c] - before[c] == (2 if c == col else 0), (dtype, before, after)
 
 
 @pytest.mark.parametrize("S", [49, 20, 32])
