@@ -358,6 +358,33 @@ __device__ __forceinline__ void gn_tree(const GnF& p, const float* part, float* 
     if (grp) __syncthreads();
 }
 
+// Both components of part[pl][ch][2] in one walk (the backward kernel's two sums: half the barriers, 8-byte LDS reads).
+// `seg` holds 2 * nseg * slabC floats.  Same summation order per component as gn_tree.
+__device__ __forceinline__ void gn_tree2(const GnF& p, const float* part, float* seg, float* c0, float* c1) {
+    const int nseg = max(1, min((int)blockDim.x / p.slabC, p.PP));
+    const f32x2* part2 = reinterpret_cast<const f32x2*>(part);
+    f32x2* seg2 = reinterpret_cast<f32x2*>(seg);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < nseg * p.slabC; idx += blockDim.x) {
+        const int ch = idx % p.slabC, sg = idx / p.slabC;
+        f32x2 t0 = {0.f, 0.f}, t1 = {0.f, 0.f};
+        int l = sg;
+        for (; l + nseg < p.PP; l += 2 * nseg) {
+            t0 += part2[l * p.slabC + ch];
+            t1 += part2[(l + nseg) * p.slabC + ch];
+        }
+        if (l < p.PP) t0 += part2[l * p.slabC + ch];
+        seg2[sg * p.slabC + ch] = t0 + t1;
+    }
+    __syncthreads();
+    for (int ch = threadIdx.x; ch < p.slabC; ch += blockDim.x) {
+        f32x2 t = {0.f, 0.f};
+        for (int sg = 0; sg < nseg; ++sg) t += seg2[sg * p.slabC + ch];
+        c0[ch] = t[0]; c1[ch] = t[1];
+    }
+    __syncthreads();
+}
+
 // Workgroup ids go to the 8 XCDs round-robin; the slabs of ONE sample (consecutive logical ids) share 64-byte sectors
 // when a slab row is narrower than a sector pair, so each XCD gets a contiguous range of logical ids: the partner
 // slab's half of a sector is then an L2 hit instead of a second fetch through the fabric.
@@ -375,9 +402,10 @@ __device__ __forceinline__ void gn_fence(Raw (&raw)[R]) {
     for (int r = 0; r < R; ++r) asm volatile("" : "+v"(raw[r]));
 }
 
-template <typename T, int N, int R>
+template <typename T, int N, int R, bool SILU>
 __global__ __launch_bounds__(512, 4) void gn_fwd_fused_kernel(const GnF p) {
     typedef typename Chk<T, N>::type Raw;
+    constexpr bool FAST = sizeof(T) == 2;                            // bf16 compute: v_rcp / fma forms (psg_common.h)
     extern __shared__ __attribute__((aligned(16))) float sm[];      // [PP][slabC] partials | [nseg][slabC] | [slabC] | [SG] | [SG]
     float* segb = sm + (int64_t)p.PP * p.slabC;
     float* chan = segb + max((int)blockDim.x, p.slabC);
@@ -431,7 +459,7 @@ __global__ __launch_bounds__(512, 4) void gn_fwd_fused_kernel(const GnF p) {
     for (int r = 0; r < R; ++r) {
         const float w = (pl + r * p.PP) < p.HW ? 1.f : 0.f;
 #pragma unroll
-        for (int e = 0; e < N; ++e) { const float d = chk_get<T, N>(raw[r], e) - mu[e]; s[e] += w * d * d; }
+        for (int e = 0; e < N; ++e) { const float d = chk_get<T, N>(raw[r], e) - mu[e]; s[e] = FAST ? __builtin_fmaf(w * d, d, s[e]) : s[e] + w * d * d; }
     }
 #pragma unroll
     for (int e = 0; e < N; ++e) row[e] = s[e];
@@ -460,19 +488,20 @@ __global__ __launch_bounds__(512, 4) void gn_fwd_fused_kernel(const GnF p) {
         if (pl + r * p.PP < p.HW) {
             float v[N];
 #pragma unroll
-            for (int e = 0; e < N; ++e) { v[e] = chk_get<T, N>(raw[r], e) * sc[e] + sh[e]; if (p.silu) v[e] = silu_f(v[e]); }
+            for (int e = 0; e < N; ++e) { v[e] = mad_t<FAST>(chk_get<T, N>(raw[r], e), sc[e], sh[e]); if (SILU) v[e] = silu_t<FAST>(v[e]); }
             chk_st<T, N>(ys + (uint32_t)(yo + r * ystep), v);
         }
         __builtin_amdgcn_sched_barrier(0);
     }
 }
 
-template <typename T, int N, int R>
+template <typename T, int N, int R, bool SILU, bool RES>
 __global__ __launch_bounds__(512, 4) void gn_bwd_fused_kernel(const GnF p) {
     typedef typename Chk<T, N>::type Raw;
-    extern __shared__ __attribute__((aligned(16))) float sm[];      // [PP][slabC][2] partials | [nseg][slabC] | [4][slabC] | 4 x [SG]
+    constexpr bool FAST = sizeof(T) == 2;
+    extern __shared__ __attribute__((aligned(16))) float sm[];      // [PP][slabC][2] partials | [nseg][slabC][2] | [4][slabC] | 4 x [SG]
     float* segb = sm + (int64_t)p.PP * p.slabC * 2;
-    float* chan = segb + max((int)blockDim.x, p.slabC);              // [0],[1]: gamma-weighted; [2],[3]: raw channel totals
+    float* chan = segb + 2 * max((int)blockDim.x, p.slabC);          // [0],[1]: gamma-weighted; [2],[3]: raw channel totals
     float* g1 = chan + 4 * p.slabC;
     float* g2 = g1 + p.SG;
     float* gmu = g2 + p.SG;          // the slab's group statistics, staged once (per-element global addresses of mean /
@@ -518,8 +547,8 @@ __global__ __launch_bounds__(512, 4) void gn_bwd_fused_kernel(const GnF p) {
         for (int e = 0; e < N; ++e) {
             const float xv = chk_get<T, N>(rx[r], e);
             float dz = chk_get<T, N>(rd[r], e);                  // (absent pixels hold dy = 0)
-            if (p.silu) dz *= silu_grad(xv * A[e] + Bc[e]);
-            a0[e] += dz * xv; a1[e] += dz;
+            if (SILU) dz *= silu_grad_t<FAST>(mad_t<FAST>(xv, A[e], Bc[e]));
+            a0[e] = mad_t<FAST>(dz, xv, a0[e]); a1[e] += dz;
         }
         __builtin_amdgcn_sched_barrier(0);      // one chunk's temporaries at a time (else hipcc interleaves all R: spills)
     }
@@ -527,8 +556,7 @@ __global__ __launch_bounds__(512, 4) void gn_bwd_fused_kernel(const GnF p) {
 #pragma unroll
     for (int e = 0; e < N; ++e) { row[2 * e] = a0[e]; row[2 * e + 1] = a1[e]; }
     // channel totals, per-sample (sum dz*xhat, sum dz) out for dgamma / dbeta, gamma-weighted group sums
-    gn_tree(p, sm, segb, chan + 2 * p.slabC, nullptr, 2, 0);
-    gn_tree(p, sm, segb, chan + 3 * p.slabC, nullptr, 2, 1);
+    gn_tree2(p, sm, segb, chan + 2 * p.slabC, chan + 3 * p.slabC);
     for (int ch = threadIdx.x; ch < p.slabC; ch += blockDim.x) {
         const float t0 = chan[2 * p.slabC + ch], t1 = chan[3 * p.slabC + ch];
         const float m_ = gmu[ch / p.Cg], r_ = grs[ch / p.Cg];
@@ -557,7 +585,7 @@ __global__ __launch_bounds__(512, 4) void gn_bwd_fused_kernel(const GnF p) {
         for (int e = 0; e < N; ++e) { P[e] = e < eb ? P_lo : P_hi; Q[e] = e < eb ? Q_lo : Q_hi; }
     }
     char* os = reinterpret_cast<char*>(p.dx) + ((int64_t)b * p.HW * p.lddx + slab * p.slabC) * ESZ;
-    const char* rb = p.dres ? reinterpret_cast<const char*>(p.dres) + ((int64_t)b * p.HW * p.lddres + slab * p.slabC) * ESZ : nullptr;
+    const char* rb = RES ? reinterpret_cast<const char*>(p.dres) + ((int64_t)b * p.HW * p.lddres + slab * p.slabC) * ESZ : nullptr;
     const uint32_t oo = (uint32_t)((pl * (int)p.lddx + c * N) * ESZ), ro = (uint32_t)((pl * (int)p.lddres + c * N) * ESZ);
     const uint32_t ostep = (uint32_t)(p.PP * (int)p.lddx * ESZ), rstep = (uint32_t)(p.PP * (int)p.lddres * ESZ);
 #pragma unroll
@@ -565,14 +593,14 @@ __global__ __launch_bounds__(512, 4) void gn_bwd_fused_kernel(const GnF p) {
         if (pl + r * p.PP < p.HW) {
             float v[N];
             Raw res = {};
-            if (rb) res = *reinterpret_cast<const Raw*>(rb + (uint32_t)(ro + r * rstep));
+            if (RES) res = *reinterpret_cast<const Raw*>(rb + (uint32_t)(ro + r * rstep));
 #pragma unroll
             for (int e = 0; e < N; ++e) {
                 const float xv = chk_get<T, N>(rx[r], e);
                 float dz = chk_get<T, N>(rd[r], e);
-                if (p.silu) dz *= silu_grad(xv * A[e] + Bc[e]);
-                v[e] = A[e] * dz - xv * P[e] + Q[e];
-                if (rb) v[e] += chk_get<T, N>(res, e);
+                if (SILU) dz *= silu_grad_t<FAST>(mad_t<FAST>(xv, A[e], Bc[e]));
+                v[e] = FAST ? __builtin_fmaf(A[e], dz, __builtin_fmaf(-xv, P[e], Q[e])) : A[e] * dz - xv * P[e] + Q[e];
+                if (RES) v[e] += chk_get<T, N>(res, e);
             }
             chk_st<T, N>(os + (uint32_t)(oo + r * ostep), v);
         }
@@ -675,7 +703,9 @@ int psg_groupnorm_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, const fl
         const size_t lds = ((size_t)f.PP * f.slabC + (f.CCs * f.PP > f.slabC ? f.CCs * f.PP : f.slabC) + f.slabC + 2 * f.SG) * sizeof(float);
         if (R && lds <= 64 * 1024) {
             const dim3 g(B * f.nslab), t(f.CCs * f.PP);
-#define PSG_GN_FWD(TT, NN, RR) hipLaunchKernelGGL((gn_fwd_fused_kernel<TT, NN, RR>), g, t, lds, s, f)
+#define PSG_GN_FWD(TT, NN, RR)                                                                     \
+    do { if (silu) hipLaunchKernelGGL((gn_fwd_fused_kernel<TT, NN, RR, true>), g, t, lds, s, f);  \
+         else hipLaunchKernelGGL((gn_fwd_fused_kernel<TT, NN, RR, false>), g, t, lds, s, f); } while (0)
             if (dtype == PSG_F32) { if (R == 4) PSG_GN_FWD(float, 4, 4); else if (R == 8) PSG_GN_FWD(float, 4, 8); else PSG_GN_FWD(float, 4, 16); }
             else { if (R == 4) PSG_GN_FWD(bf16_t, 8, 4); else if (R == 8) PSG_GN_FWD(bf16_t, 8, 8); else PSG_GN_FWD(bf16_t, 8, 16); }
 #undef PSG_GN_FWD
@@ -726,12 +756,18 @@ int psg_groupnorm_bwd_res(const void* dy, int64_t lddy, const void* x, int64_t l
         f.x = x; f.dy = dy; f.dres = dres; f.dx = dx; f.gamma = gamma; f.beta = beta; f.mean = const_cast<float*>(mean);
         f.rstd = const_cast<float*>(rstd); f.chan_ws = (float*)ws; f.ldx = ldx; f.lddy = lddy; f.lddres = lddres; f.lddx = lddx;
         f.B = B; f.HW = HW; f.C = C; f.G = G; f.silu = silu;
-        int R = gn_fused_plan(f, dtype == PSG_BF16 ? 4 : 2, 256, 8);                 // 8-byte chunks, <= 8 per lane and tensor
+        // 8-byte chunks, <= 8 per lane and tensor (16 fit the register file since the v_rcp forms - 120 VGPRs - and let the
+        // 27x27 slabs run in 256 lanes, but measured no faster: 640 vs 648 us over the U-Net's eight shapes)
+        int R = gn_fused_plan(f, dtype == PSG_BF16 ? 4 : 2, 256, 8);
         if (!R) R = gn_fused_plan(f, dtype == PSG_BF16 ? 4 : 2, 512, 8);
-        const size_t lds = ((size_t)f.PP * f.slabC * 2 + (f.CCs * f.PP > f.slabC ? f.CCs * f.PP : f.slabC) + 4 * f.slabC + 4 * f.SG) * sizeof(float);
+        const size_t lds = ((size_t)f.PP * f.slabC * 2 + 2 * (f.CCs * f.PP > f.slabC ? f.CCs * f.PP : f.slabC) + 4 * f.slabC + 4 * f.SG) * sizeof(float);
         if (R && lds <= 64 * 1024) {
             const dim3 g(B * f.nslab), t(f.CCs * f.PP);
-#define PSG_GN_BWD(TT, NN, RR) hipLaunchKernelGGL((gn_bwd_fused_kernel<TT, NN, RR>), g, t, lds, s, f)
+#define PSG_GN_BWD(TT, NN, RR)                                                                                  \
+    do { if (silu && dres) hipLaunchKernelGGL((gn_bwd_fused_kernel<TT, NN, RR, true, true>), g, t, lds, s, f);  \
+         else if (silu) hipLaunchKernelGGL((gn_bwd_fused_kernel<TT, NN, RR, true, false>), g, t, lds, s, f);    \
+         else if (dres) hipLaunchKernelGGL((gn_bwd_fused_kernel<TT, NN, RR, false, true>), g, t, lds, s, f);    \
+         else hipLaunchKernelGGL((gn_bwd_fused_kernel<TT, NN, RR, false, false>), g, t, lds, s, f); } while (0)
             if (dtype == PSG_F32) { if (R == 4) PSG_GN_BWD(float, 2, 4); else PSG_GN_BWD(float, 2, 8); }
             else { if (R == 4) PSG_GN_BWD(bf16_t, 4, 4); else PSG_GN_BWD(bf16_t, 4, 8); }
 #undef PSG_GN_BWD

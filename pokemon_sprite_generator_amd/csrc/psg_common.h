@@ -84,6 +84,23 @@ __device__ __forceinline__ float silu_grad(float x) {
     float s = sigmoidf_(x);
     return s * (1.0f + x * (1.0f - s));
 }
+// bf16 compute path (FAST): v_rcp_f32 (1 ulp) instead of the IEEE division (v_div_scale x2 / v_div_fmas / v_div_fixup + 4
+// fma: the division was 30-40 % of the vector instructions of the fused GroupNorm kernels) and fused multiply-adds; the
+// exact-fp32 path keeps the division and the unfused forms (its results do not change).
+template <bool FAST> __device__ __forceinline__ float sigmoid_t(float x) {
+    if (FAST) return __builtin_amdgcn_rcpf(1.0f + __expf(-x));
+    return sigmoidf_(x);
+}
+template <bool FAST> __device__ __forceinline__ float silu_t(float x) { return x * sigmoid_t<FAST>(x); }
+template <bool FAST> __device__ __forceinline__ float silu_grad_t(float x) {
+    const float s = sigmoid_t<FAST>(x);
+    if (FAST) return s * __builtin_fmaf(x, 1.0f - s, 1.0f);
+    return s * (1.0f + x * (1.0f - s));
+}
+template <bool FAST> __device__ __forceinline__ float mad_t(float a, float b, float c) {      // a * b + c
+    if (FAST) return __builtin_fmaf(a, b, c);
+    return a * b + c;
+}
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float gelu_grad(float x) {
     float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
@@ -95,7 +112,7 @@ __device__ __forceinline__ float gelu_grad(float x) {
 // ~16 VALU operations instead of ~60 for erff + expf: the GELU epilogues of the FFN GEMMs were as long as their K loops.
 __device__ __forceinline__ void gelu_both_fast(float x, float& y, float& dy) {
     const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __frcp_rn(1.0f + 0.3275911f * z);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);   // v_rcp_f32, 1 ulp (__frcp_rn is the 11-instruction IEEE division)
     const float e = __expf(-z * z);
     const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
     const float h = 0.5f - 0.5f * poly * e;                      // 0.5 * erf(|z|)
