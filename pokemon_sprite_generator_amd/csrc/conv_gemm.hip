@@ -23,7 +23,8 @@ static int choose_and_launch(const ConvP& p, int dtype, hipStream_t s) {
         if (force == -2) { const char* e = getenv("PSG_CONV_TILE"); force = e ? atoi(e) : -1; }
         const int cand[5][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 160}, {64, 160}};
         double eff[5] = {1.0, 0.78, 0.55, 1.0, 0.70};      // measured relative MFMA efficiency of the tile shapes
-        if (p.KT <= 10) eff[1] = 1.1;                      // K <= 640: 3 resident 128x64 workgroups hide the short K loop's ends
+        // (a K <= 640 boost for 128x64 - three resident workgroups hiding the short loop ends - paid before the epilogue was
+        //  specialised per kind; since then 128x128 wins those layers by 10 %: gemm_direct.py)
         if (dtype != PSG_BF16 || p.ntap > 0) eff[3] = eff[4] = 0.0;   // 160 = 2 x 5 x 16: only the 16x16x32 bf16 tiles divide it
         const double slots = 512.0;                        // resident workgroups on the chip (2 per CU)
         double best = -1.0;

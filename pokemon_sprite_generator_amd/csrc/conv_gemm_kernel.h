@@ -445,6 +445,20 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
             }
         }
     }
+    wait_vmcnt<0>();
+    __syncthreads();                       // the DMA of tile 0 has landed for every wave
+    for (int kt = 0; kt + 1 < KT; ++kt) {
+        const int buf = kt & 1;
+        // buffer buf^1 was last read in step kt-1, which every wave finished before the barrier below
+        load_tiles(kt + 1, buf ^ 1);
+        compute(buf);
+        wait_vmcnt<0>();                   // (asm LDS-DMA is invisible to hipcc: the wait is ours)
+        __syncthreads();                   // tile kt+1 is in LDS, tile kt no longer needed
+    }
+    // Last K step (peeled): no tile is left to request, so the staged epilogue's row-major residual / saved-derivative
+    // fetch goes out NOW and flies under the step's MFMAs.  vmcnt retires in order: issued any earlier these HBM-latency
+    // loads sit in front of a tile DMA and the wait for that tile waits for them too (behind the first tile, as before,
+    // they stretched every workgroup's prologue: a residual cost a K<=1280 Linear 35-50 % more than its bandwidth).
     if constexpr (FT16) {
         if (resg && p.epi_lds) {
 #pragma unroll
@@ -458,16 +472,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
             }
         }
     }
-    wait_vmcnt<0>();
-    __syncthreads();                       // the DMA of tile 0 has landed for every wave
-    for (int kt = 0; kt < KT; ++kt) {
-        const int buf = kt & 1;
-        // buffer buf^1 was last read in step kt-1, which every wave finished before the barrier below
-        if (kt + 1 < KT) load_tiles(kt + 1, buf ^ 1);
-        compute(buf);
-        wait_vmcnt<0>();                   // (asm LDS-DMA is invisible to hipcc: the wait is ours)
-        __syncthreads();                   // tile kt+1 is in LDS, tile kt no longer needed
-    }
+    compute((KT - 1) & 1);
+    __syncthreads();                       // every wave is done with the tile buffers: the epilogue reuses them
 
     // ---- fused epilogue: phase 1 loads every bias / residual operand of the tile, phase 2 computes and stores ----
     if constexpr (FT16) {

@@ -483,6 +483,44 @@ __global__ void prep_weight_kernel(const float* __restrict__ w, int ohwi, T* __r
     }
 }
 
+// The per-step case: bf16 OHWI shadow -> wd only (the data-gradient operand wd[ci][tap][co], a transposition of the
+// shadow itself).  16-byte loads and stores (8 values), transposed through a bf16 LDS tile; the generic kernel below moves
+// 2 bytes per lane and load (1.3 TB/s over the 146 launches of a step).  Needs O % 8 == 0 and I % 8 == 0.
+__global__ __launch_bounds__(256) void prep_wd_bf16_kernel(const bf16_t* __restrict__ w, bf16_t* __restrict__ wd, int O, int I, int taps, int64_t kpd) {
+    __shared__ unsigned short t[64][66];                  // [co][ci], 132-byte rows: the 8 strided 2-byte reads of a store chunk hit distinct banks
+    const int ci0 = blockIdx.x * 64, co0 = blockIdx.y * 64, tap = blockIdx.z;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int co = k * 32 + (tid >> 3), ch = tid & 7;
+        uint4 v = {0u, 0u, 0u, 0u};
+        if (co0 + co < O && ci0 + ch * 8 < I) v = *reinterpret_cast<const uint4*>(w + ((int64_t)(co0 + co) * taps + tap) * I + ci0 + ch * 8);
+        uint32_t* d = reinterpret_cast<uint32_t*>(&t[co][ch * 8]);      // (rows are 4-byte aligned: 132 = 4 * 33)
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int id = tid + 256 * k;
+        const int ci = id >> 3, q = (id & 7) * 8;
+        if (ci0 + ci < I && co0 + q < O) {
+            uint32_t o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (uint32_t)t[q + 2 * e][ci] | ((uint32_t)t[q + 2 * e + 1][ci] << 16);
+            const uint4 v = {o[0], o[1], o[2], o[3]};
+            *reinterpret_cast<uint4*>(wd + (int64_t)(ci0 + ci) * kpd + (int64_t)tap * O + co0 + q) = v;
+        }
+    }
+    if (blockIdx.y == 0 && tap == 0) {                    // zero the K padding of these rows
+        const int64_t k0 = (int64_t)taps * O;
+        const int npad = (int)(kpd - k0);
+        for (int e = tid; e < 64 * npad; e += 256) {
+            const int r = e / npad, c = e - r * npad;
+            if (ci0 + r < I) wd[(int64_t)(ci0 + r) * kpd + k0 + c] = (bf16_t)0.f;
+        }
+    }
+}
+
 // OHWI master (w[co][tap][ci], the training layout) or any 1x1/linear weight: one 64co x 64ci tile of one tap per
 // workgroup.  Shift-only index math, 256-byte coalesced reads, 8/16-byte stores of 4 elements along ci (wf) and
 // along co (wd, transposed through LDS).  Needs O % 4 == 0 and I % 4 == 0.
@@ -879,7 +917,10 @@ int psg_prep_weight(const void* w, int w_dtype, int w_layout, void* wf, void* wd
         const dim3 g((I + 63) / 64, (O + 63) / 64, taps);
         if (w_dtype == PSG_BF16) {
             PSG_REQUIRE(dtype == PSG_BF16, PSG_ERR_DTYPE, "prep_weight: a bf16 source prepares bf16 weights only");
-            hipLaunchKernelGGL((prep_weight_ohwi_kernel<bf16_t, bf16_t>), g, dim3(256), 0, s, (const bf16_t*)w, (bf16_t*)wf, (bf16_t*)wd, O, I, taps, kpf, kpd);
+            if (!wf && O % 8 == 0 && I % 8 == 0)
+                hipLaunchKernelGGL(prep_wd_bf16_kernel, g, dim3(256), 0, s, (const bf16_t*)w, (bf16_t*)wd, O, I, taps, kpd);
+            else
+                hipLaunchKernelGGL((prep_weight_ohwi_kernel<bf16_t, bf16_t>), g, dim3(256), 0, s, (const bf16_t*)w, (bf16_t*)wf, (bf16_t*)wd, O, I, taps, kpf, kpd);
         } else {
             DISPATCH_DTYPE(dtype,
                 hipLaunchKernelGGL((prep_weight_ohwi_kernel<float, float>), g, dim3(256), 0, s, (const float*)w, (float*)wf, (float*)wd, O, I, taps, kpf, kpd),
