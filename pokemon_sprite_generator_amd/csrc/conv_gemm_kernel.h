@@ -133,15 +133,19 @@ __device__ __forceinline__ void conv_value(const ConvP& p, int m, int n, f32x4& 
 // arithmetic, branch-free.  EK_GENERIC keeps the run-time form (SiLU / ReLU / tanh, activation-gradient backward forms,
 // and every fp32 launch: the exact path's arithmetic order does not change).
 enum { EK_PLAIN = 0, EK_DROP = 1, EK_GELU = 2, EK_GELU_DROP = 3, EK_DMUL = 4, EK_GENERIC = 5 };
-template <typename T, int EK>
+// AUX_LATER: stop before the aux operand (the residual, or EK_DMUL's saved derivative) enters - conv_aux_k applies it
+// later to the same fp32 value, so the result is the one-step form's bit for bit.
+template <typename T, int EK, bool AUX_LATER = false>
 __device__ __forceinline__ void conv_value_k(const ConvP& p, int m, int n, f32x4& v, f32x4& pre, f32x4 bias4, f32x4 ra4, f32x4 aux4) {
     if constexpr (EK == EK_GENERIC) { conv_value<T>(p, m, n, v, pre, bias4, ra4, aux4); return; }
     else {
         v += bias4 + ra4;
         pre = v;
         if constexpr (EK == EK_DMUL) {                    // backward form, derivative saved by the forward launch; no dropout
-            v *= aux4;
-            v *= p.alpha;
+            if constexpr (!AUX_LATER) {
+                v *= aux4;
+                v *= p.alpha;
+            }
             return;
         }
         f32x4 d = {1.f, 1.f, 1.f, 1.f};
@@ -163,8 +167,14 @@ __device__ __forceinline__ void conv_value_k(const ConvP& p, int m, int n, f32x4
         }
         if (p.flags & PSG_CONV_SAVE_DACT) pre = d;
         v *= p.alpha;
-        v += aux4;
+        if constexpr (!AUX_LATER) v += aux4;
     }
+}
+// the aux step of conv_value_k<.., AUX_LATER = true> on one value
+template <int EK>
+__device__ __forceinline__ float conv_aux_k(const ConvP& p, float v, float aux) {
+    if constexpr (EK == EK_DMUL) return (v * aux) * p.alpha;
+    else return v + aux;
 }
 
 template <typename T>
@@ -427,11 +437,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
     uint4 res_row[FT16 ? E_NIT : 1];
     if constexpr (FT16) {
 #pragma unroll
-        for (int i = 0; i < NA; ++i) {
-            const int n = n0 + wn * WN + i * 16 + 4 * kq;
-            bias4[i] = (p.bias && n < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n) : zero4;
-        }
-#pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int mt_ = m0 + wm * WM + j * 16 + l16;
             rows[j] = -1; smp[j] = 0;
@@ -460,6 +465,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
     // loads sit in front of a tile DMA and the wait for that tile waits for them too (behind the first tile, as before,
     // they stretched every workgroup's prologue: a residual cost a K<=1280 Linear 35-50 % more than its bandwidth).
     if constexpr (FT16) {
+        // (the bias too: even as L2 hits its loads, issued behind the first tile, held every workgroup's first wait for
+        //  0.5-1 us - a bias cost a K = 640 Linear 12-18 %)
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int n = n0 + wn * WN + i * 16 + 4 * kq;
+            bias4[i] = (p.bias && n < p.N) ? *reinterpret_cast<const f32x4*>(p.bias + n) : zero4;
+        }
         if (resg && p.epi_lds) {
 #pragma unroll
             for (int it = 0; it < E_NIT; ++it) {
@@ -591,6 +603,66 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
                     }
                 }
             };
+            // A residual (or EK_DMUL's saved derivative) WITHOUT `preact`: the operand was fetched row-major (res_row, issued in
+            // the last K step).  Turning it into the accumulator layout through LDS put a second dependent round trip
+            // (rows -> LDS -> cells) in FRONT of the arithmetic, and the wait for the fetch with it: on the K <= 1280 layers a
+            // residual cost 1.4-1.6x a bias-only epilogue.  Here the cells go out first, as fp32 (two halves of WM/2 pixels so
+            // that the 4-byte image fits the wave's region), and the operand joins in the ROW-major domain, in fp32, right
+            // before the one rounding to bf16: same bits, no round trip, and the fetch has the whole staging to land.
+            auto stage_aux = [&]() {
+                constexpr int HR = WM / 2, NBH = NB / 2;
+                constexpr int PITCHF = WN * 4 + 16;                 // bytes; (PITCHF/4) mod 64 = 4: the 8-lane groups of ds_write_b128 cover 32 banks
+                constexpr int NITH = NIT / 2;                        // row-major chunks (8 channels) per lane and half
+                static_assert(HR * PITCHF <= WM * PITCH, "fp32 half image must fit the wave's staging region");
+                T* dy = reinterpret_cast<T*>(p.y);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+#pragma unroll
+                    for (int jj = 0; jj < NBH; ++jj) {
+                        const int j = h * NBH + jj;
+                        f32x4 ra4[NA];
+#pragma unroll
+                        for (int i = 0; i < NA; ++i) {
+                            const int n = n0 + wn * WN + i * 16 + 4 * kq;
+                            ra4[i] = (rag && rows[j] >= 0 && n < p.N) ? load4<T>(rag + (int64_t)smp[j] * p.ldra + n) : zero4;
+                        }
+#pragma unroll
+                        for (int i = 0; i < NA; ++i) {
+                            const int n = n0 + wn * WN + i * 16 + 4 * kq;
+                            f32x4 v = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                            f32x4 pre;
+                            conv_value_k<T, EK, true>(p, rows[j], n, v, pre, bias4[i], ra4[i], zero4);
+                            *reinterpret_cast<f32x4*>(reg + (jj * 16 + l16) * PITCHF + (i * 16 + 4 * kq) * 4) = v;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int it = 0; it < NITH; ++it) {
+                        const int idx = it * 64 + lane;              // chunk inside the half: same (row, chunk) walk as res_row
+                        const int row = idx / CPRW, chk = idx - row * CPRW;
+                        const int mt_ = m0 + wm * WM + h * HR + row, n = n0 + wn * WN + chk * 8;
+                        if (mt_ < p.M && n < p.N) {
+                            const f32x4 lo = *reinterpret_cast<const f32x4*>(reg + row * PITCHF + chk * 32);
+                            const f32x4 hi = *reinterpret_cast<const f32x4*>(reg + row * PITCHF + chk * 32 + 16);
+                            const uint4 a = res_row[h * NITH + it];
+                            const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+                            bf16x8 o;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float a0 = __uint_as_float(aw[e] << 16), a1 = __uint_as_float(aw[e] & 0xFFFF0000u);
+                                const float v0 = e < 2 ? lo[2 * e] : hi[2 * e - 4], v1 = e < 2 ? lo[2 * e + 1] : hi[2 * e - 3];
+                                o[2 * e] = (bf16_t)conv_aux_k<EK>(p, v0, a0);
+                                o[2 * e + 1] = (bf16_t)conv_aux_k<EK>(p, v1, a1);
+                            }
+                            *reinterpret_cast<bf16x8*>(dy + (int64_t)conv_out_m<MODE>(p, mt_) * p.ldy + n) = o;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            };
+            if constexpr (NB % 2 == 0 && EK != EK_GENERIC && MODE != 3 && NIT % 2 == 0 && ((WM / 2) * CPRW) % 64 == 0) {
+                if (resg && !p.preact) { stage_aux(); return; }
+            }
             if constexpr (NB % 2 == 0 && BN != 160 && MODE != 3) {   // (160-wide and parity-class kernels have no scalar registers to spare)
                 if (p.preact && !resg) { stage_both(); return; }
             }
