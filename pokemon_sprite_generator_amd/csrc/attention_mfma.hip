@@ -252,6 +252,8 @@ __global__ __launch_bounds__(256, (ND <= 5 ? 2 : 1)) void attn_dq_mfma(const Att
         for (int t = 0; t < NDT; ++t)
 #pragma unroll
             for (int e = 0; e < 16; ++e) dacc[t][e] = 0.f;
+        const DropRow dr = drop_row(p.seed, ((uint64_t)bh * p.L + l) * (uint64_t)((p.S + 1) >> 1));
+        const uint32_t t16 = p.drop_thresh >> 16;
         for (int kt = 0; kt < nkt; ++kt) {
             f32x16 st, dp;
 #pragma unroll
@@ -263,21 +265,20 @@ __global__ __launch_bounds__(256, (ND <= 5 ? 2 : 1)) void attn_dq_mfma(const Att
                 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st, 0, 0, 0);
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, gf[ks], dp, 0, 0, 0);
             }
-            const uint64_t prow = ((uint64_t)bh * p.L + l) * (uint64_t)((p.S + 1) >> 1);
+            // Branch-free: a key >= S meets a zero K row in dQ^T += K^T . dS^T, a query >= L is a column that is never
+            // stored, and every value here is finite either way (lse = del = 0 for absent queries, scores of absent keys 0).
+            if (p.drop_thresh) {
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {          // registers r, r+1 hold keys 2k, 2k+1: one hash for both
+                    const uint32_t hh = drop_hash_row(dr, (uint32_t)(kt * 16 + (acc_row(r, fh) >> 1)));
+                    dp[r] = (hh & 0xFFFFu) >= t16 ? dp[r] * p.drop_scale : 0.f;
+                    dp[r + 1] = (hh >> 16) >= t16 ? dp[r + 1] * p.drop_scale : 0.f;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int key = kt * 32 + acc_row(r, fh);
-                float ds = 0.f;
-                if (lok && key < p.S) {
-                    const float pr = __expf(st[r] * p.scale - lse);
-                    float dpr = dp[r];
-                    if (p.drop_thresh) {               // (the two registers of a key pair compute the same hash: CSE'd)
-                        const uint32_t hh = drop_hash_pair(p.seed, prow + (uint32_t)(key >> 1));
-                        dpr = drop_keep_half(hh, key & 1, p.drop_thresh) ? dpr * p.drop_scale : 0.f;
-                    }
-                    ds = pr * (dpr - del) * p.scale;
-                }
-                st[r] = ds;
+                const float pr = __expf(st[r] * p.scale - lse);
+                st[r] = pr * (dp[r] - del) * p.scale;
             }
             const bf16x8 sf0 = pack8(st, 0), sf1 = pack8(st, 1);
 #pragma unroll

@@ -159,6 +159,22 @@ __device__ __forceinline__ uint32_t drop_hash_pair(uint64_t seed, uint64_t pair)
     const uint32_t lo = (uint32_t)pair, hi = (uint32_t)(pair >> 32);
     return mix32(lo * 0x9E3779B1u + (uint32_t)seed + ((hi * 0x85EBCA77u) ^ (uint32_t)(seed >> 32)));
 }
+// Pair hashes along ONE row of a mask: drop_hash_pair(seed, base + off), off < 2^32, with the 64-bit half of the index
+// done once per row (the attention kernels hash 8-16 pairs per lane and key tile: the 64-bit index arithmetic per pair
+// was half of their vector instructions).  Same bits as drop_hash_pair, carry into the high word included.
+struct DropRow { uint32_t lo, k0, k1; };
+__device__ __forceinline__ DropRow drop_row(uint64_t seed, uint64_t base) {
+    const uint32_t hi = (uint32_t)(base >> 32), s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);
+    DropRow r;
+    r.lo = (uint32_t)base;
+    r.k0 = s0 + ((hi * 0x85EBCA77u) ^ s1);
+    r.k1 = s0 + (((hi + 1u) * 0x85EBCA77u) ^ s1);
+    return r;
+}
+__device__ __forceinline__ uint32_t drop_hash_row(const DropRow& r, uint32_t off) {
+    const uint32_t lo = r.lo + off;
+    return mix32(lo * 0x9E3779B1u + (lo < r.lo ? r.k1 : r.k0));
+}
 __device__ __forceinline__ bool drop_keep_half(uint32_t h, int odd, uint32_t thresh) {
     return ((odd ? (h >> 16) : (h & 0xFFFFu)) >= (thresh >> 16));
 }
