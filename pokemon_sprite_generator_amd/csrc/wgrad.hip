@@ -28,6 +28,7 @@ struct WgP {
     int B, Hi, Wi, Cin, Ho, Wo, Cout, ks, stride, pad;
     int M, Q, taps;
     int rtiles, qtiles, splits, steps_per_split;   // steps of BKP pixels
+    int BR;                                        // output rows (co) per tile: 128, or 160 = exact tiling of Cout = 320
     float inv_HoWo, inv_Wo;
     uint32_t x_bytes, dy_bytes;
 };
@@ -43,7 +44,10 @@ template <> struct WgCfg<float> { static constexpr int BKP = 32; static constexp
 //     (m mod HoWo, m mod Wo) trackers per pass
 //   2 pointwise (1x1 conv / Linear): as 1 with no border at all
 // The per-lane address VALU work is what bounds this kernel (it competes with the MFMAs for issue slots).
-template <typename T, int GEOM>
+// BR = 160 (bf16, GEOM 1/2, Cout % 160 == 0): the dY tile is [64 pixels][160 co] with 320-byte rows - 80 dwords, so four
+// consecutive rows already start 16 banks apart and the chunk key shrinks to ((row >> 3) & 1) << 1; each wave owns
+// 80 co x 64 q = 5 x 4 MFMA tiles.  Three 128-row tiles over Cout = 320 leave the third half empty (18 % of the launch).
+template <typename T, int GEOM, int BR = 128>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // the LDS-DMA builtin exists only in the device pass
     constexpr int CH = Elem<T>::CH;
@@ -52,7 +56,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
     constexpr int CPR = 128 / CH;            // 16-byte chunks per 128-channel row
     constexpr int RPP = 256 / CPR;           // rows per staging pass
     constexpr int NPASS = BKP / RPP;         // = 4
-    constexpr int TILE_BYTES = BKP * ROWB;
+    constexpr int TILE_BYTES = BKP * ROWB;                         // the gathered-X tile (128 q)
+    constexpr int AROWB = BR * (int)sizeof(T);                     // dY tile row
+    constexpr int ATILE_BYTES = BKP * AROWB;
+    constexpr int STAGE_BYTES = ATILE_BYTES + TILE_BYTES;
+    constexpr int ACH = BR / CH;                                   // 16-byte chunks per dY tile row
+    constexpr int NPA = BKP * ACH / 256;                           // dY staging passes (4; 5 for BR = 160)
+    static_assert(BR == 128 || (BR == 160 && sizeof(T) == 2 && GEOM != 0), "160-row tiles: bf16, stride-1 geometries");
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [buf][A tile | B tile]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -71,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
     const int split = lid / tiles;
     const int tix = lid - split * tiles;
     const int rt = tix % p.rtiles, qt = tix / p.rtiles;
-    const int co0 = rt * 128, q0 = qt * 128;
+    const int co0 = rt * BR, q0 = qt * 128;
 
     // Tiles go global -> LDS by LDS-DMA (wave-uniform base + lane*16: whole 256/512-byte rows, unpadded).  For bf16
     // the transposed fragment reads (4 consecutive pixel rows x 64-byte column windows per half-wave) are made
@@ -136,6 +146,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
     const int g_shift = (p.pad * p.Wi + p.pad) * ldxB;
     const u32x4 xrs_g = make_rsrc(reinterpret_cast<const char*>(p.x) - g_shift, p.x_bytes + (uint32_t)g_shift);
     int g_b = g_m * ldxB + (b_kh * p.Wi + b_kw) * ldxB + b_ci * ESZ;
+    // BR = 160: lane e = 256 j + tid of pass j sits at (row e / 20, physical chunk e % 20) of the dY image and fetches the
+    // logical chunk (physical ^ key(row)); rows >= M lie beyond the descriptor's extent and read as zeros (no per-row test)
+    uint32_t a_voff[BR == 160 ? NPA : 1];
+    if constexpr (BR == 160) {
+#pragma unroll
+        for (int j = 0; j < NPA; ++j) {
+            const int e = j * 256 + tid, row = e / ACH, pc = e - row * ACH;
+            const int lc = pc ^ (((row >> 3) & 1) << 1);
+            a_voff[j] = (uint32_t)(((step0 * BKP + row) * (int)p.lddy + co0 + lc * CH) * ESZ);
+        }
+    }
     const int a_pass = RPP * (int)p.lddy * ESZ, b_pass = RPP * ldxB;       // uniform
     const int st_rm = BKP % HoWo, st_wo = BKP % p.Wo;
     const int rm_lo = ho_lo * p.Wo;
@@ -147,8 +168,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
         g_wo[j] = g_rm[j] % p.Wo;
     }
     auto load_tiles = [&](int buf) {   // DMA the rows at the current odometer state into LDS buffer buf, then advance
-        const uint32_t adst = lds_wave + (uint32_t)buf * 2 * TILE_BYTES;
-        const uint32_t bdst = adst + TILE_BYTES;
+        const uint32_t adst = lds_wave + (uint32_t)buf * STAGE_BYTES;
+        const uint32_t bdst = adst + ATILE_BYTES;
         if constexpr (GEOM == 0) {
 #pragma unroll
             for (int j = 0; j < NPASS; ++j) {
@@ -181,8 +202,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
                     int wo = g_wo[j] + st_wo; wo -= wo >= p.Wo ? p.Wo : 0; g_wo[j] = wo;
                 }
                 const uint32_t boff = ok ? (uint32_t)g_b : OOB;
-                lds_dma16s(yrs, adst + j * PASS_BYTES, aoff, (uint32_t)(j * a_pass));
+                if constexpr (BR == 128) lds_dma16s(yrs, adst + j * PASS_BYTES, aoff, (uint32_t)(j * a_pass));
                 lds_dma16s(xrs_g, bdst + j * PASS_BYTES, boff, (uint32_t)(j * b_pass));
+            }
+            if constexpr (BR == 160) {
+#pragma unroll
+                for (int j = 0; j < NPA; ++j) {
+                    lds_dma16(yrs, adst + j * PASS_BYTES, a_voff[j]);
+                    a_voff[j] += (uint32_t)a_step;
+                }
             }
             g_m += BKP; g_a += a_step; g_b += BKP * ldxB;
         }
@@ -192,10 +220,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
     // traffic); fp32: 2x2 tiles of v_mfma_f32_32x32x2_f32
     constexpr bool FT16 = sizeof(T) == 2;
     constexpr int NA = FT16 ? 4 : 2, AE = FT16 ? 4 : 16;
+    constexpr int NR = FT16 ? BR / 32 : 2;            // row (co) tiles per wave: 4, or 5 for BR = 160
     typedef float AccT __attribute__((ext_vector_type(AE)));
-    AccT acc[NA][NA];
+    AccT acc[NR][NA];
 #pragma unroll
-    for (int i = 0; i < NA; ++i)
+    for (int i = 0; i < NR; ++i)
 #pragma unroll
         for (int j = 0; j < NA; ++j)
 #pragma unroll
@@ -203,9 +232,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
     // bias gradient = column sums of the dY tile: the waves of tile column 0 multiply their dY fragments with a
     // ones operand (every accumulator column then holds sum_k dY[k][co]); wave-uniform condition
     const bool do_bias = p.bws != nullptr && qt == 0 && wc == 0;
-    AccT accb[NA];
+    AccT accb[NR];
 #pragma unroll
-    for (int i = 0; i < NA; ++i)
+    for (int i = 0; i < NR; ++i)
 #pragma unroll
         for (int e = 0; e < AE; ++e) accb[i][e] = 0.f;
 
@@ -216,8 +245,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
     for (int st = 0; st < nsteps; ++st) {
         const int buf = st & 1;
         if (st + 1 < nsteps) load_tiles(buf ^ 1);      // buffer buf^1 was last read in step st-1 (barrier below)
-        const char* ab = smem + buf * 2 * TILE_BYTES;
-        const char* bb = ab + TILE_BYTES;
+        const char* ab = smem + buf * STAGE_BYTES;
+        const char* bb = ab + ATILE_BYTES;
         if constexpr (FT16) {
             // Transposed fragment reads.  Lane -> (16-lane group g, q4 = row of the 4x16 block, p4 = 4-column piece):
             // group g of k-step s2 reads pixel rows 32*s2 + 8g + {0..3} and + {4..7}, columns tile + 4*p4..+3, and
@@ -227,21 +256,27 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
             const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
             const int key0 = (q4 << 2) | ((2 * g) & 3), key1 = (q4 << 2) | ((2 * g + 1) & 3);   // swizzle keys of the 2 rows
             const int rowb = (8 * g + q4) * ROWB + 8 * (p4 & 1);
-            const int chA = wr * 8 + (p4 >> 1), chB = wc * 8 + (p4 >> 1);      // 16-byte chunk of tile 0 (+2 per tile)
-            bf16x8 af[2][4], bf[2][4];
+            const int rowa = (8 * g + q4) * AROWB + 8 * (p4 & 1);
+            const int chA = wr * (BR / 16) + (p4 >> 1), chB = wc * 8 + (p4 >> 1);      // 16-byte chunk of tile 0 (+2 per tile)
+            // chunk keys of the dY image: the 256-byte-row swizzle, or for 320-byte rows ((row >> 3) & 1) << 1 = (g & 1) << 1
+            const int ka0 = BR == 160 ? ((g & 1) << 1) : key0, ka1 = BR == 160 ? ((g & 1) << 1) : key1;
+            bf16x8 af[2][NR], bf[2][4];
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
+                const char* ra = ab + s2 * 32 * AROWB + rowa;
+                const char* rb = bb + s2 * 32 * ROWB + rowb;
+#pragma unroll
+                for (int i = 0; i < NR; ++i) {
+                    s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ra + (((chA + 2 * i) ^ ka0) << 4)));
+                    s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ra + 4 * AROWB + (((chA + 2 * i) ^ ka1) << 4)));
+                    s16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                    af[s2][i] = *reinterpret_cast<bf16x8*>(&av);
+                }
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    const char* ra = ab + s2 * 32 * ROWB + rowb;
-                    const char* rb = bb + s2 * 32 * ROWB + rowb;
-                    s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ra + (((chA + 2 * i) ^ key0) << 4)));
-                    s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(ra + 4 * ROWB + (((chA + 2 * i) ^ key1) << 4)));
                     s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(rb + (((chB + 2 * i) ^ key0) << 4)));
                     s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(rb + 4 * ROWB + (((chB + 2 * i) ^ key1) << 4)));
-                    s16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
                     s16x8 bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
-                    af[s2][i] = *reinterpret_cast<bf16x8*>(&av);
                     bf[s2][i] = *reinterpret_cast<bf16x8*>(&bv);
                 }
             }
@@ -249,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < NR; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s2][i], bf[s2][j], acc[i][j], 0, 0, 0);
             if (do_bias) {
@@ -258,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s2][i], ones, accb[i], 0, 0, 0);
+                    for (int i = 0; i < NR; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[s2][i], ones, accb[i], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
         } else {
@@ -292,10 +327,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
         if constexpr (FT16) {
             if ((lane & 15) == 0) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < NR; ++i)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int co = co0 + wr * 64 + i * 16 + 4 * (lane >> 4) + r;
+                        const int co = co0 + wr * (BR / 2) + i * 16 + 4 * (lane >> 4) + r;
                         if (co < p.Cout) bw[co] = accb[i][r] * p.scale;
                     }
             }
@@ -318,10 +353,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
             const int q = q0 + wc * 64 + j * 16 + l16;
             if (q >= p.Q) continue;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < NR; ++i) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int co = co0 + wr * 64 + i * 16 + 4 * kq + r;
+                    const int co = co0 + wr * (BR / 2) + i * 16 + 4 * kq + r;
                     if (co < p.Cout) wsb[(int64_t)co * p.Q + q] = acc[i][j][r] * p.scale;
                 }
             }
@@ -402,7 +437,14 @@ static void wgrad_plan(const psg_wgrad_desc* d, WgP& p) {
     p.M = d->B * d->Ho * d->Wo;
     p.taps = d->ksize * d->ksize;
     p.Q = p.taps * d->Cin;
-    p.rtiles = (d->Cout + 127) / 128;
+    {
+        // 160-row tiles where they tile Cout exactly and 128 does not (Cout = 320: 2 tiles instead of 2.5 -> 3)
+        static int off = -1;
+        if (off < 0) { const char* e = getenv("PSG_WGRAD_BR160"); off = (e && atoi(e) == 0) ? 1 : 0; }
+        const bool same = d->stride == 1 && d->Hi == d->Ho && d->Wi == d->Wo;
+        p.BR = (!off && d->dtype == PSG_BF16 && same && d->Cout % 160 == 0 && d->Cout % 128 != 0) ? 160 : 128;
+    }
+    p.rtiles = (d->Cout + p.BR - 1) / p.BR;
     p.qtiles = (p.Q + 127) / 128;
     const int total_steps = (p.M + BKP - 1) / BKP;
     const int tiles = p.rtiles * p.qtiles;
@@ -411,7 +453,7 @@ static void wgrad_plan(const psg_wgrad_desc* d, WgP& p) {
     // one slab of traffic to the deterministic sum pass.  Picking the split count that merely "fills the chip"
     // leaves e.g. 1035 blocks = 2.02 rounds (a third of the time on 11 stragglers); this picks 966 or 483 instead.
     const int kSlots = 512;
-    const double step_us = d->dtype == PSG_BF16 ? 1.05 : 8.0, fixed_steps = 6.0;
+    const double step_us = (d->dtype == PSG_BF16 ? 1.05 : 8.0) * (p.BR == 160 ? 1.25 : 1.0), fixed_steps = 6.0;
     const double slab_us = (double)d->Cout * p.Q * 4.0 / 4.0e6;          // one fp32 slab through HBM at ~4 TB/s
     const bool native = d->dw_layout == PSG_W_OHWI || p.taps == 1;
     int max_splits = (total_steps + 7) / 8;                               // at least 8 K steps per split
@@ -447,6 +489,8 @@ int psg_wgrad_init_attrs(void) {
     PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<float, G>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32 * 512));
     PSG_WG_ATTR(0) PSG_WG_ATTR(1) PSG_WG_ATTR(2)
 #undef PSG_WG_ATTR
+    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<bf16_t, 1, 160>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (320 + 256)));
+    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<bf16_t, 2, 160>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (320 + 256)));
     return PSG_OK;
 }
 
@@ -512,7 +556,10 @@ int psg_conv_wgrad(const psg_wgrad_desc* d, psg_stream_t stream) {
 #define PSG_WG_LAUNCH(G)                                                                                               \
         if (d->dtype == PSG_BF16) hipLaunchKernelGGL((wgrad_kernel<bf16_t, G>), dim3(grid), dim3(256), 4 * 64 * 256, s, p); \
         else hipLaunchKernelGGL((wgrad_kernel<float, G>), dim3(grid), dim3(256), 4 * 32 * 512, s, p);
-        if (geom == 0) { PSG_WG_LAUNCH(0) } else if (geom == 1) { PSG_WG_LAUNCH(1) } else { PSG_WG_LAUNCH(2) }
+        if (p.BR == 160) {
+            if (geom == 1) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 1, 160>), dim3(grid), dim3(256), 2 * 64 * (320 + 256), s, p);
+            else hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 160>), dim3(grid), dim3(256), 2 * 64 * (320 + 256), s, p);
+        } else if (geom == 0) { PSG_WG_LAUNCH(0) } else if (geom == 1) { PSG_WG_LAUNCH(1) } else { PSG_WG_LAUNCH(2) }
 #undef PSG_WG_LAUNCH
     }
     PSG_LAUNCH_CHECK("wgrad");

@@ -233,7 +233,7 @@ def test_groupnorm(psg, dtype, B, H, C, eps, silu):
 CONV_CASES = [  # B, H, Cin, Cout, ks, stride
     (2, 7, 64, 128, 3, 1), (3, 5, 64, 64, 3, 1), (2, 9, 64, 64, 3, 2), (2, 14, 128, 64, 3, 2), (2, 27, 64, 64, 3, 2),
     (2, 4, 128, 64, 1, 1), (2, 27, 8, 320, 3, 1), (2, 27, 320, 8, 3, 1), (1, 4, 2560, 128, 3, 1), (5, 7, 192, 320, 3, 1),
-    (1, 27, 320, 320, 3, 1),
+    (1, 27, 320, 320, 3, 1), (2, 14, 64, 320, 1, 1), (3, 7, 96, 160, 3, 1),      # (Cout 320 / 160: the weight gradient's 160-row tiles)
 ]
 
 
