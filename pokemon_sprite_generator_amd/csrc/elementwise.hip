@@ -400,10 +400,13 @@ __global__ void adamw_kernel4(float* __restrict__ p, const float* __restrict__ g
         const int64_t i1 = i0 + stride;
         const bool two = i1 < n4;
         const int64_t j1 = two ? i1 : i0;
-        f32x4 G[2] = {reinterpret_cast<const f32x4*>(g)[i0], reinterpret_cast<const f32x4*>(g)[j1]};
-        f32x4 P[2] = {reinterpret_cast<f32x4*>(p)[i0], reinterpret_cast<f32x4*>(p)[j1]};
-        f32x4 M[2] = {reinterpret_cast<f32x4*>(m)[i0], reinterpret_cast<f32x4*>(m)[j1]};
-        f32x4 V[2] = {reinterpret_cast<f32x4*>(v)[i0], reinterpret_cast<f32x4*>(v)[j1]};
+        // (nontemporal loads / stores measured: -1 % at best, +17 % on large grids - plain accesses)
+        auto ld = [](const float* a, int64_t i) { return reinterpret_cast<const f32x4*>(a)[i]; };
+        auto stv = [](float* a, int64_t i, f32x4 x) { reinterpret_cast<f32x4*>(a)[i] = x; };
+        f32x4 G[2] = {ld(g, i0), ld(g, j1)};
+        f32x4 P[2] = {ld(p, i0), ld(p, j1)};
+        f32x4 M[2] = {ld(m, i0), ld(m, j1)};
+        f32x4 V[2] = {ld(v, i0), ld(v, j1)};
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
 #pragma unroll
@@ -417,10 +420,10 @@ __global__ void adamw_kernel4(float* __restrict__ p, const float* __restrict__ g
                 P[u][e] = pi; M[u][e] = mi; V[u][e] = vi;
             }
         }
-        reinterpret_cast<f32x4*>(p)[i0] = P[0]; reinterpret_cast<f32x4*>(m)[i0] = M[0]; reinterpret_cast<f32x4*>(v)[i0] = V[0];
+        stv(p, i0, P[0]); stv(m, i0, M[0]); stv(v, i0, V[0]);
         if (shadow) store4<bf16_t>(shadow + 4 * i0, P[0]);
         if (two) {
-            reinterpret_cast<f32x4*>(p)[i1] = P[1]; reinterpret_cast<f32x4*>(m)[i1] = M[1]; reinterpret_cast<f32x4*>(v)[i1] = V[1];
+            stv(p, i1, P[1]); stv(m, i1, M[1]); stv(v, i1, V[1]);
             if (shadow) store4<bf16_t>(shadow + 4 * i1, P[1]);
         }
     }
@@ -737,7 +740,9 @@ static int adamw_launch(float* p, const float* g, float* m, float* v, int64_t n,
     const bool vec = n % 4 == 0 && aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v) && (!shadow_bf16 || aligned8(shadow_bf16));
     PSG_REQUIRE(!shadow_bf16 || vec, PSG_ERR_ALIGN, "adamw: the bf16 shadow needs n %% 4 == 0 and 16-byte aligned buffers");
     if (vec) {
-        hipLaunchKernelGGL(adamw_kernel4, dim3(grid_for(n / 4, 256, 8192)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n / 4, lr,
+        // grid: 262144 workgroups at most (2-3 trips of the 2 x float4 loop on the 640 M-parameter arena): 3.15 ms against
+        // 3.35 ms with 8192 long-running ones (6.1 vs 5.7 TB/s)
+        hipLaunchKernelGGL(adamw_kernel4, dim3(grid_for(n / 4, 256, 262144)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n / 4, lr,
                            beta1, beta2, eps, weight_decay, bc1, bc2_sqrt, normsq, max_norm, skip_flag, (bf16_t*)shadow_bf16, sc);
     } else {
         hipLaunchKernelGGL(adamw_kernel, dim3(grid_for(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr,
