@@ -269,6 +269,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
                     x_hb[j] = i; x_wb[j] = jj;
                     x_base[j] = ((b * p.Hi + i) * p.Wi + jj) * (int)p.ldx * ESZ + sc * 16;
                 } else { x_hb[j] = -100000; x_wb[j] = -100000; x_base[j] = 0; }
+            } else if (MODE != 2 && p.taps == 1 && p.stride == 1 && m < p.M) {
+                // pointwise (every Linear, the 1x1 convs): the source pixel IS the output pixel - no (b, ho, wo) decode
+                // (two integer divisions per staging pass in a prologue that a K <= 1280 tile cannot amortise)
+                x_hb[j] = 0; x_wb[j] = 0;
+                x_base[j] = m * (int)p.ldx * ESZ + sc * 16;
             } else if (m < p.M) {
                 const int b = m / HoWo, rm = m - b * HoWo;
                 const int ho = rm / p.Wo, wo = rm - ho * p.Wo;
