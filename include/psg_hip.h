@@ -183,8 +183,10 @@ int64_t psg_groupnorm_bwd_workspace_bytes(int B, int C);
  * ------------------------------------------------------------------------- */
 /* PSG_CONV_SAVE_DACT (forward form): `preact` receives the epilogue's DERIVATIVE d = act'(u) * mask/(1-p) instead of
  *   the pre-activation u, so that backward multiplies by a loaded value instead of re-evaluating erf/exp and the mask.
- * PSG_CONV_DACT_MUL (backward form): `dact_u` holds that saved derivative: value *= dact_u (no act', drop_p must be 0). */
-enum psg_conv_flags { PSG_CONV_SAVE_DACT = 1, PSG_CONV_DACT_MUL = 2 };
+ * PSG_CONV_DACT_MUL (backward form): `dact_u` holds that saved derivative: value *= dact_u (no act', drop_p must be 0).
+ * PSG_CONV_GENERIC_EPILOGUE: run the launch through the run-time (one-step) epilogue instead of its specialised copy -
+ * same results bit for bit; exists so that tests can hold the two against each other in one process. */
+enum psg_conv_flags { PSG_CONV_SAVE_DACT = 1, PSG_CONV_DACT_MUL = 2, PSG_CONV_GENERIC_EPILOGUE = 4 };
 typedef struct psg_conv_desc {
     int32_t dtype;               /* psg_dtype of x, w, y, rowadd, residual, preact, dact_u */
     int32_t B, Hi, Wi, Cin;      /* gather source x: [B, Hi, Wi, Cin] */

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("PSG_LIB_PATH") or os.path.join(_HERE, "libpsg_hip.so"
 
 PSG_F32, PSG_BF16 = 0, 1
 ACT_NONE, ACT_SILU, ACT_GELU, ACT_RELU, ACT_TANH = 0, 1, 2, 3, 4
-CONV_SAVE_DACT, CONV_DACT_MUL = 1, 2          # enum psg_conv_flags
+CONV_SAVE_DACT, CONV_DACT_MUL, CONV_GENERIC_EPILOGUE = 1, 2, 4          # enum psg_conv_flags
 # enum psg_flag: bits of the per-step NaN/Inf flag word
 FLAG_NOISY_BAD, FLAG_T_RANGE, FLAG_PRED_BAD, FLAG_LOSS_BAD, FLAG_FALLBACK, FLAG_INPUT_BAD, FLAG_SKIP_MASK = 1, 2, 4, 8, 16, 32, 47
 

@@ -96,7 +96,7 @@ int psg_conv_fwd(const psg_conv_desc* d, psg_stream_t stream) {
     PSG_REQUIRE(!d->dact_u || (aligned16(d->dact_u) && d->ld_dact % 4 == 0), PSG_ERR_ALIGN, "conv_fwd: dact_u alignment");
     PSG_REQUIRE(d->drop_p >= 0.f && d->drop_p < 1.f, PSG_ERR_ARG, "conv_fwd: drop_p %f", d->drop_p);
     PSG_REQUIRE(!(d->residual && d->dact_u), PSG_ERR_ARG, "conv_fwd: residual and dact_u are mutually exclusive");
-    PSG_REQUIRE((d->flags & ~(PSG_CONV_SAVE_DACT | PSG_CONV_DACT_MUL)) == 0, PSG_ERR_ARG, "conv_fwd: unknown flags 0x%x", d->flags);
+    PSG_REQUIRE((d->flags & ~(PSG_CONV_SAVE_DACT | PSG_CONV_DACT_MUL | PSG_CONV_GENERIC_EPILOGUE)) == 0, PSG_ERR_ARG, "conv_fwd: unknown flags 0x%x", d->flags);
     PSG_REQUIRE(!(d->flags & PSG_CONV_SAVE_DACT) || (d->preact && !d->dact_u), PSG_ERR_ARG, "conv_fwd: SAVE_DACT needs preact (forward form)");
     PSG_REQUIRE(!(d->flags & PSG_CONV_DACT_MUL) || (d->dact_u && d->drop_p == 0.f), PSG_ERR_ARG,
                 "conv_fwd: DACT_MUL needs dact_u and drop_p = 0 (the saved derivative already carries the mask)");
@@ -131,7 +131,7 @@ int psg_conv_fwd(const psg_conv_desc* d, psg_stream_t stream) {
         p.epi_lds = (!off && d->dtype == PSG_BF16 && d->Cout % 8 == 0 && d->ldy % 8 == 0 && (!d->preact || d->ld_preact % 8 == 0) &&
                      (!d->residual || d->ld_residual % 8 == 0) && (!d->dact_u || d->ld_dact % 8 == 0)) ? 1 : 0;
     }
-    { static int gen = -1; if (gen < 0) { const char* e = getenv("PSG_EPI_KINDS"); gen = (e && atoi(e) == 0) ? 1 : 0; } p.epi_generic = gen; }
+    { static int gen = -1; if (gen < 0) { const char* e = getenv("PSG_EPI_KINDS"); gen = (e && atoi(e) == 0) ? 1 : 0; } p.epi_generic = (gen || (d->flags & PSG_CONV_GENERIC_EPILOGUE)) ? 1 : 0; }
     p.drop_thresh = d->drop_p > 0.f ? drop_thresh(d->drop_p) : 0u;
     p.drop_scale = d->drop_p > 0.f ? 1.0f / (1.0f - d->drop_p) : 1.0f;
     p.drop_seed = d->drop_seed;

@@ -581,3 +581,55 @@ def test_flat_arena_adamw_matches_torch(psg):
                           "param_groups": sd["param_groups"]})
     run(opt2, 2, 3)
     ga.release()
+
+
+@pytest.mark.parametrize("M,K,N", [(1000, 192, 256), (777, 640, 320), (300, 128, 64), (8200, 256, 512)])
+def test_conv_epilogue_kinds_bitwise(psg, M, K, N):
+    """The bf16 staged epilogue exists once per kind (plain / dropout / GELU / GELU+dropout / saved-derivative product), with
+    the residual joining in the row-major domain and `preact` + y staged side by side; PSG_CONV_GENERIC_EPILOGUE runs the
+    same launch through the run-time, one-step form.  The two must agree BIT FOR BIT - y and, where written, `preact` -
+    over ragged M (tile edges), the 128x128 / 128x160 / 64x64 tiles and every operand combination the U-Net issues."""
+    import ctypes as C
+    from pokemon_sprite_generator_amd import ops, _lib
+    from pokemon_sprite_generator_amd._lib import ConvDesc
+    lib = _lib.init(0)
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device="cpu").manual_seed(M + K + N)
+    r = lambda *s: torch.randn(*s, generator=g)
+    x = r(M, K).bfloat16().to(DEV)
+    w = (r(N, K) * 0.05).to(DEV)
+    wf, wd = ops.WeightCache.get(w, torch.bfloat16, True)
+    bias = r(N).to(DEV)
+    res = r(M, N).bfloat16().to(DEV)
+    sav = r(M, N).bfloat16().to(DEV)
+    rowadd = r(7, N).bfloat16().to(DEV)
+
+    def run(generic, **kw):
+        y = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=DEV)
+        pre = torch.full((M, N), 7.0, dtype=torch.bfloat16, device=DEV)
+        d = ConvDesc()
+        d.dtype = _lib.PSG_BF16
+        d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout = M, 1, 1, K, 1, 1, N
+        d.ksize, d.stride, d.pad, d.transposed, d.act = 1, 1, 0, 0, kw.get("act", 0)
+        d.alpha, d.drop_p, d.drop_seed = kw.get("alpha", 1.0), kw.get("drop", 0.0), 99
+        d.flags = kw.get("flags", 0) | (_lib.CONV_GENERIC_EPILOGUE if generic else 0)
+        d.ldx, d.ldy, d.ldw = K, N, 0
+        d.x, d.w, d.y = x.data_ptr(), wf.data_ptr(), y.data_ptr()
+        if kw.get("bias"): d.bias = bias.data_ptr()
+        if kw.get("res"): d.residual, d.ld_residual = res.data_ptr(), N
+        if kw.get("pre"): d.preact, d.ld_preact = pre.data_ptr(), N
+        if kw.get("dact"): d.dact_u, d.ld_dact = sav.data_ptr(), N
+        _lib.check(lib.psg_conv_fwd(C.byref(d), st), "psg_conv_fwd")
+        torch.cuda.synchronize()
+        return y, pre
+
+    variants = [dict(), dict(bias=1), dict(bias=1, res=1), dict(bias=1, res=1, drop=0.1, alpha=0.5), dict(bias=1, drop=0.1),
+                dict(bias=1, act=_lib.ACT_GELU), dict(bias=1, act=_lib.ACT_GELU, res=1), dict(bias=1, act=_lib.ACT_GELU, drop=0.1, pre=1, flags=_lib.CONV_SAVE_DACT),
+                dict(bias=1, act=_lib.ACT_GELU, pre=1, flags=_lib.CONV_SAVE_DACT), dict(bias=1, pre=1), dict(bias=1, pre=1, res=1),
+                dict(dact=1, flags=_lib.CONV_DACT_MUL, alpha=0.7), dict(bias=1, act=_lib.ACT_SILU, res=1)]
+    for kw in variants:
+        ya, pa = run(False, **kw)
+        yb, pb = run(True, **kw)
+        assert torch.equal(ya, yb), f"y differs for {kw}"
+        assert torch.equal(pa, pb), f"preact differs for {kw}"
+        assert torch.isfinite(ya.float()).all()
