@@ -140,6 +140,12 @@ int psg_upsample_bilinear_bwd(const void* dy, int64_t lddy, void* dx, int64_t ld
 /* y = a + b (elementwise, strided rows); used for gradient fan-in of skip tensors. */
 int psg_add(const void* a, int64_t lda, const void* b, int64_t ldb, void* y, int64_t ldy, int64_t rows,
             int cols, int dtype, psg_stream_t stream);
+/* y = a (+ b (+ c)), b / c may be NULL (c needs b): row-strided [rows][cols] operands, 16-byte chunks (cols and row strides
+ * multiples of 8 bf16 / 4 fp32), the fp32 sum rounded once.  One source: the strided copy of a skip tensor into its half of
+ * the decoder's concat buffer (reference unet.py:480-504 `torch.cat([x, skip], dim=1)`: the x half is written there by
+ * its producer); three: the gradient fan-in of a skip tensor (its three consumers) in one pass. */
+int psg_sum_rows(const void* a, int64_t lda, const void* b, int64_t ldb, const void* c, int64_t ldc, void* y, int64_t ldy,
+                 int64_t rows, int cols, int dtype, psg_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * GroupNorm (+ fused SiLU) — unet.py:79,89,115,127,397 (eps 1e-5) and

@@ -300,6 +300,39 @@ __global__ void add_kernel(const T* __restrict__ a, int64_t lda, const T* __rest
     }
 }
 
+// y = a (+ b (+ c)): row-strided operands, 16-byte chunks, ONE rounding of the fp32 sum.  One source = a strided copy
+// (a skip tensor into its half of a concat buffer), three = the gradient fan-in of a skip tensor (next encoder stage +
+// the two decoder blocks that read it) in one pass instead of autograd's clone + add + add.
+template <typename T>
+__global__ void sum_rows_kernel(const T* __restrict__ a, int64_t lda, const T* __restrict__ b, int64_t ldb, const T* __restrict__ c,
+                                int64_t ldc, T* __restrict__ y, int64_t ldy, int64_t rows, int cols) {
+    constexpr int CH = 16 / (int)sizeof(T);
+    typedef float VecT __attribute__((ext_vector_type(CH)));
+    const int cpr = cols / CH;
+    const int64_t n = rows * cpr;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / cpr;
+        const int col = (int)(i - r * cpr) * CH;
+        uint4 ra = *reinterpret_cast<const uint4*>(a + r * lda + col), rb = ra, rc = ra;
+        if (b) rb = *reinterpret_cast<const uint4*>(b + r * ldb + col);
+        if (c) rc = *reinterpret_cast<const uint4*>(c + r * ldc + col);
+        if (b) {
+            const T* pa = reinterpret_cast<const T*>(&ra);
+            const T* pb = reinterpret_cast<const T*>(&rb);
+            const T* pc = reinterpret_cast<const T*>(&rc);
+            T o[CH];
+#pragma unroll
+            for (int e = 0; e < CH; ++e) {
+                float v = (float)pa[e] + (float)pb[e];
+                if (c) v += (float)pc[e];
+                o[e] = (T)v;
+            }
+            ra = *reinterpret_cast<const uint4*>(o);
+        }
+        *reinterpret_cast<uint4*>(y + r * ldy + col) = ra;
+    }
+}
+
 template <typename T>
 __global__ void dropout_apply_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy,
                                      int64_t rows, int cols, uint32_t thresh, uint64_t seed, float scale) {
@@ -870,6 +903,22 @@ int psg_add(const void* a, int64_t lda, const void* b, int64_t ldb, void* y, int
         hipLaunchKernelGGL(add_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)a, lda, (const float*)b, ldb, (float*)y, ldy, rows, cols),
         hipLaunchKernelGGL(add_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, (bf16_t*)y, ldy, rows, cols));
     PSG_LAUNCH_CHECK("add");
+    return PSG_OK;
+}
+
+int psg_sum_rows(const void* a, int64_t lda, const void* b, int64_t ldb, const void* c, int64_t ldc, void* y, int64_t ldy,
+                 int64_t rows, int cols, int dtype, psg_stream_t stream) {
+    PSG_REQUIRE(a && y && (b || !c), PSG_ERR_ARG, "sum_rows: null pointer (c needs b)");
+    const int CH = dtype == PSG_BF16 ? 8 : 4;
+    PSG_REQUIRE(dtype == PSG_F32 || dtype == PSG_BF16, PSG_ERR_DTYPE, "sum_rows: dtype %d", dtype);
+    PSG_REQUIRE(rows > 0 && cols > 0 && cols % CH == 0 && lda % CH == 0 && ldy % CH == 0 && (!b || ldb % CH == 0) && (!c || ldc % CH == 0),
+                PSG_ERR_SHAPE, "sum_rows: cols / row strides must be multiples of %d", CH);
+    PSG_REQUIRE(aligned16(a) && aligned16(y) && (!b || aligned16(b)) && (!c || aligned16(c)), PSG_ERR_ALIGN, "sum_rows: 16-byte alignment");
+    const int g = grid_for(rows * (cols / CH), 256, 65536);
+    DISPATCH_DTYPE(dtype,
+        hipLaunchKernelGGL(sum_rows_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)a, lda, (const float*)b, ldb, (const float*)c, ldc, (float*)y, ldy, rows, cols),
+        hipLaunchKernelGGL(sum_rows_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, lda, (const bf16_t*)b, ldb, (const bf16_t*)c, ldc, (bf16_t*)y, ldy, rows, cols));
+    PSG_LAUNCH_CHECK("sum_rows");
     return PSG_OK;
 }
 

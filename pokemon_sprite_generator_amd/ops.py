@@ -353,13 +353,123 @@ def _param_grad(param, compute):
 
 
 # ---------------------------------------------------------------------------
+# producing into a slice of a larger buffer (the decoder's concat) and the skip tensors' gradient fan-in
+# ---------------------------------------------------------------------------
+class OutSlot:
+    """Where an op should produce its result: a row-strided view (same shape as the result) of a larger buffer.  A plain
+    Python object on purpose - handed to an autograd Function as a tensor it would count as an INPUT returned as an output."""
+
+    def __init__(self, view):
+        self.view = view
+
+
+def _out_rows(out, shape, dtype, device):
+    """(tensor to write, its row stride): a fresh contiguous tensor, or the OutSlot's view after checking that it can be
+    addressed as rows (uniform row stride, 16-byte aligned rows)."""
+    if out is None:
+        return torch.empty(shape, dtype=dtype, device=device), shape[-1]
+    v = out.view
+    if tuple(v.shape) != tuple(shape) or v.dtype != dtype or v.device != device:
+        raise _lib.PsgError(f"out slot {tuple(v.shape)} {v.dtype} does not match the result {tuple(shape)} {dtype}")
+    ld = v.stride(-2)
+    esz = v.element_size()
+    ok = v.stride(-1) == 1 and (v.data_ptr() % 16) == 0 and (ld * esz) % 16 == 0
+    expect = ld
+    for i in range(v.dim() - 2, -1, -1):
+        if v.shape[i] != 1 and v.stride(i) != expect:
+            ok = False
+        expect *= v.shape[i]
+    if not ok:
+        raise _lib.PsgError(f"out slot with strides {tuple(v.stride())} is not row-addressable")
+    return v, ld
+
+
+def sum_rows(a, b=None, c=None, out=None):
+    """a (+ b (+ c)) over row-strided [..., C] tensors in one pass (psg_sum_rows); `out` may be a strided view."""
+    lib = _lib_for(a)
+    ar, lda = _rows(a)
+    C_ = ar.shape[-1]
+    rows = 1
+    for n_ in ar.shape[:-1]:
+        rows *= int(n_)
+    br, ldb = _rows(b) if b is not None else (None, 0)
+    cr, ldc = _rows(c) if c is not None else (None, 0)
+    if out is None:
+        out = torch.empty(a.shape, dtype=a.dtype, device=a.device)
+    o, ldo = _out_rows(OutSlot(out), tuple(a.shape), a.dtype, a.device)
+    check(lib.psg_sum_rows(ptr(ar), lda, ptr(br) if br is not None else None, ldb, ptr(cr) if cr is not None else None, ldc,
+                           ptr(o), ldo, rows, C_, dtype_code(a.dtype), stream_ptr()), "psg_sum_rows")
+    return out
+
+
+class _ConcatSlotFn(torch.autograd.Function):
+    """torch.cat([x, skip], dim=-1) where x ALREADY lies in buf[..., :C1] (its producer wrote it there through an OutSlot)
+    and skip was copied into buf[..., C1:] when the buffer was made: forward hands out the buffer, backward the two
+    slices of its gradient (views: the consumers take row-strided gradients)."""
+
+    @staticmethod
+    def forward(ctx, x, skip, holder):
+        buf = holder.view
+        C1 = x.shape[-1]
+        if x.data_ptr() != buf.data_ptr() or x.stride() != buf[..., :C1].stride() or tuple(x.shape[:-1]) != tuple(buf.shape[:-1]):
+            raise _lib.PsgError("concat_slot: x was not produced in the buffer's slot")
+        ctx.C1 = C1
+        return buf
+
+    @staticmethod
+    def backward(ctx, dcat):
+        return dcat[..., :ctx.C1], dcat[..., ctx.C1:], None
+
+
+class ConcatSlot:
+    """The decoder's concat without the concat: `slot = ConcatSlot(skip, C1)` allocates [.., C1 + C2] and copies the skip
+    half (one strided pass, psg_sum_rows); the op producing x gets `out=slot.out`; `slot.cat(x, skip)` is the node whose
+    result is the full buffer (reference unet.py:480-504)."""
+
+    def __init__(self, skip, C1):
+        shape = tuple(skip.shape[:-1]) + (C1 + skip.shape[-1],)
+        self.buf = torch.empty(shape, dtype=skip.dtype, device=skip.device)
+        with torch.no_grad():
+            sum_rows(skip.detach(), out=self.buf[..., C1:])
+        self.out = OutSlot(self.buf[..., :C1])
+
+    def cat(self, x, skip):
+        return _ConcatSlotFn.apply(x, skip, OutSlot(self.buf))
+
+
+class _Fan3Fn(torch.autograd.Function):
+    """One tensor, three consumers: the three gradients are summed in ONE pass (fp32 sum, one rounding) instead of
+    autograd's clone of the first (a strided concat-gradient slice) plus two adds."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x), x.view_as(x), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g0, g1, g2):
+        gs = [g for g in (g0, g1, g2) if g is not None]
+        if not gs:
+            return None
+        if len(gs) == 1:
+            return gs[0]
+        return sum_rows(gs[0], gs[1], gs[2] if len(gs) > 2 else None)
+
+
+def fan3(x):
+    """(x, x, x) for a skip tensor's three consumers (next encoder stage, two decoder blocks); see _Fan3Fn."""
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return x, x, x
+    return _Fan3Fn.apply(x)
+
+
+# ---------------------------------------------------------------------------
 # conv / linear
 # ---------------------------------------------------------------------------
 class _ConvFn(torch.autograd.Function):
     """y = residual + alpha * drop(act(conv(x, W) + bias + rowadd[b]))  — psg_conv_fwd / psg_conv_wgrad."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, rowadd, residual, stride, act, alpha, drop_p, seed):
+    def forward(ctx, x, weight, bias, rowadd, residual, stride, act, alpha, drop_p, seed, out=None):
         lib = _lib_for(x)
         dtype = x.dtype
         is_conv = weight.dim() == 4
@@ -377,7 +487,7 @@ class _ConvFn(torch.autograd.Function):
         geom = (B, Hi, Wi, Ho, Wo, ks, stride, pad)
         need_dx = ctx.needs_input_grad[0]
         wf, wd = WeightCache.get(weight, dtype, need_dx)
-        y = torch.empty(out_shape, dtype=dtype, device=x.device)
+        y, ldy = _out_rows(out, out_shape, dtype, x.device)
         has_epi = (act != ACT_NONE)
         any_grad = any(ctx.needs_input_grad)
         preact = torch.empty(out_shape, dtype=dtype, device=x.device) if (has_epi and any_grad) else None
@@ -387,7 +497,7 @@ class _ConvFn(torch.autograd.Function):
         ra = None
         if rowadd is not None:
             ra = rowadd if (rowadd.stride(-1) == 1 and rowadd.stride(0) % 4 == 0 and rowadd.data_ptr() % 16 == 0) else rowadd.contiguous()
-        _conv_launch(lib, dtype, xr, ldx, wf, 0, y, Cout, geom, Cin, Cout, bias=bias, rowadd=ra, residual=res_r, ld_res=ld_res,
+        _conv_launch(lib, dtype, xr, ldx, wf, 0, y, ldy, geom, Cin, Cout, bias=bias, rowadd=ra, residual=res_r, ld_res=ld_res,
                      preact=preact, act=act, alpha=alpha, drop_p=drop_p, seed=seed)
         ctx.save_for_backward(xr, weight, preact)
         ctx.bias_param, ctx.weight_param = bias, weight
@@ -451,17 +561,18 @@ class _ConvFn(torch.autograd.Function):
             db = _param_grad(ctx.bias_param, bias_only)
         if has_ra and ctx.needs_input_grad[3]:
             dra = _colsum(lib, g, ldg, Ho * Wo, B, Cout, dtype, dtype, keep2d=True)
-        return dx, dw, db, dra, d_res, None, None, None, None, None
+        return dx, dw, db, dra, d_res, None, None, None, None, None, None
 
 
-def conv2d(x, weight, bias=None, stride=1, rowadd=None, residual=None, act=ACT_NONE, alpha=1.0, drop_p=0.0, seed=0):
-    """x: [B,H,W,Cin] channels-last; weight: fp32 OIHW parameter (3x3 pad 1, or 1x1).  nn.Conv2d of unet.py."""
-    return _ConvFn.apply(x, weight, bias, rowadd, residual, stride, act, alpha, drop_p, seed)
+def conv2d(x, weight, bias=None, stride=1, rowadd=None, residual=None, act=ACT_NONE, alpha=1.0, drop_p=0.0, seed=0, out=None):
+    """x: [B,H,W,Cin] channels-last; weight: fp32 OIHW parameter (3x3 pad 1, or 1x1).  nn.Conv2d of unet.py.
+    `out`: a row-strided tensor of the output's shape to produce the result in (`OutSlot`, see `concat_slot`)."""
+    return _ConvFn.apply(x, weight, bias, rowadd, residual, stride, act, alpha, drop_p, seed, out)
 
 
-def linear(x, weight, bias=None, residual=None, act=ACT_NONE, alpha=1.0, drop_p=0.0, seed=0):
+def linear(x, weight, bias=None, residual=None, act=ACT_NONE, alpha=1.0, drop_p=0.0, seed=0, out=None):
     """x: [..., Cin]; weight: fp32 [Cout, Cin] parameter.  nn.Linear of unet.py, with the fused epilogue."""
-    return _ConvFn.apply(x, weight, bias, None, residual, 1, act, alpha, drop_p, seed)
+    return _ConvFn.apply(x, weight, bias, None, residual, 1, act, alpha, drop_p, seed, out)
 
 
 _FFN_SAVE_DACT = os.environ.get("PSG_FFN_SAVE_DACT", "1") != "0"     # 0: save u, re-evaluate gelu'(u) and the mask in backward (A/B)
@@ -477,7 +588,7 @@ class _FFNFn(torch.autograd.Function):
     first Linear's data gradient (no autograd add)."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, alpha, drop_p, seed1, seed2):
+    def forward(ctx, x, w1, b1, w2, b2, alpha, drop_p, seed1, seed2, out=None):
         lib = _lib_for(x)
         dtype = x.dtype
         C, Hd = w1.shape[1], w1.shape[0]
@@ -488,12 +599,12 @@ class _FFNFn(torch.autograd.Function):
         wf2, wd2 = WeightCache.get(w2, dtype, need)
         u = torch.empty((M, Hd), dtype=dtype, device=x.device) if need else None
         hmid = torch.empty((M, Hd), dtype=dtype, device=x.device)
-        y = torch.empty(x.shape, dtype=dtype, device=x.device)
+        y, ldy = _out_rows(out, tuple(x.shape), dtype, x.device)
         g1 = (M, 1, 1, 1, 1, 1, 1, 0)
         # `u` receives gelu'(W1 x + b1) * mask1 / (1 - p), not the pre-activation: backward multiplies by it
         _conv_launch(lib, dtype, xr, ldx, wf1, 0, hmid, Hd, g1, C, Hd, bias=b1, preact=u, act=ACT_GELU, drop_p=drop_p, seed=seed1,
                      flags=_lib.CONV_SAVE_DACT if (u is not None and _FFN_SAVE_DACT) else 0)
-        _conv_launch(lib, dtype, hmid, Hd, wf2, 0, y, C, g1, Hd, C, bias=b2, residual=xr, ld_res=ldx, alpha=alpha, drop_p=drop_p, seed=seed2)
+        _conv_launch(lib, dtype, hmid, Hd, wf2, 0, y, ldy, g1, Hd, C, bias=b2, residual=xr, ld_res=ldx, alpha=alpha, drop_p=drop_p, seed=seed2)
         ctx.save_for_backward(xr, u, hmid, w1, w2)
         ctx.params = (w1, b1, w2, b2)
         ctx.meta = (M, C, Hd, ldx, alpha, drop_p, seed1, seed2, tuple(x.shape), wd1, wd2)
@@ -546,12 +657,12 @@ class _FFNFn(torch.autograd.Function):
             _conv_launch(lib, dtype, gu, Hd, wd1, 0, dx, C, geo, Hd, C, transposed=True, residual=dyr, ld_res=lddy)
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dw1, db1 = wgrad(xr, ldx, gu, Hd, w1p, b1p, C, Hd)
-        return dx, dw1, db1, dw2, db2, None, None, None, None
+        return dx, dw1, db1, dw2, db2, None, None, None, None, None
 
 
-def ffn(x, w1, b1, w2, b2, alpha, drop_p=0.0, seed1=0, seed2=0):
+def ffn(x, w1, b1, w2, b2, alpha, drop_p=0.0, seed1=0, seed2=0, out=None):
     """x + alpha * drop(W2 drop(gelu(W1 x + b1)) + b2), fused forward epilogues and backward forms (see _FFNFn)."""
-    return _FFNFn.apply(x, w1, b1, w2, b2, alpha, drop_p, seed1, seed2)
+    return _FFNFn.apply(x, w1, b1, w2, b2, alpha, drop_p, seed1, seed2, out)
 
 
 class _CrossInProjFn(torch.autograd.Function):

@@ -22,6 +22,7 @@ from . import ops
 from .ops import ACT_GELU, ACT_NONE, ACT_SILU
 
 _FUSED_FFN = os.environ.get("PSG_FFN_FUSE", "1") != "0"
+_CONCAT_SLOTS = os.environ.get("PSG_CONCAT_SLOTS", "1") != "0"     # 0: torch.cat in the decoder, autograd sums the skip gradients (A/B)
 
 ATTN_DROPOUT = 0.05   # nn.MultiheadAttention(dropout=0.05), nn.Dropout(0.05): unet.py:160-187
 
@@ -104,8 +105,8 @@ class ResBlock(nn.Module):
         self.skip_conv = nn.Conv2d(in_channels, out_channels, kernel_size=1) if in_channels != out_channels else nn.Identity()
         self.compute_dtype = torch.float32
 
-    def nhwc(self, x, temb, pooled):
-        """x [B,H,W,Cin], temb [B,128], pooled [B,256] in the compute dtype."""
+    def nhwc(self, x, temb, pooled, out=None):
+        """x [B,H,W,Cin], temb [B,128], pooled [B,256] in the compute dtype; `out`: ops.OutSlot for the result."""
         # (h, x): x's second consumer below is the skip path - its gradient joins inside the GroupNorm backward
         h, x = ops.group_norm_split(x, self.norm1.weight, self.norm1.bias, self.norm1.num_groups, self.norm1.eps, silu=True)
         # per-sample additive vector: time_proj(temb) + text_proj(pooled)  (unet.py:119-124), fused into conv1's epilogue
@@ -117,7 +118,7 @@ class ResBlock(nn.Module):
             skip = ops.conv2d(x, self.skip_conv.weight, self.skip_conv.bias)
         else:
             skip = x
-        return ops.conv2d(h, self.conv2.weight, self.conv2.bias, residual=skip)
+        return ops.conv2d(h, self.conv2.weight, self.conv2.bias, residual=skip, out=out)
 
     def forward(self, x: torch.Tensor, time_emb: torch.Tensor, text_emb: torch.Tensor) -> torch.Tensor:
         dt = self.compute_dtype
@@ -147,9 +148,11 @@ class CrossAttentionBlock(nn.Module):
                 _small_xavier(layer)
         self.compute_dtype = torch.float32
 
-    def nhwc(self, x, text):
-        """x [B,H,W,C] (== tokens [B,L,C]); text [B,S,text_dim]; compute dtype."""
+    def nhwc(self, x, text, out=None):
+        """x [B,H,W,C] (== tokens [B,L,C]); text [B,S,text_dim]; compute dtype; `out`: ops.OutSlot for the result."""
         B, H, W, C = x.shape
+        if out is not None:
+            out = ops.OutSlot(out.view.reshape(B, H * W, C))        # (a view: the slot's H and W are adjacent in memory)
         p = ATTN_DROPOUT if self.training else 0.0
         seeds = [_SeedStream.next() for _ in range(4)] if p > 0 else [0, 0, 0, 0]
         tok = x.reshape(B, H * W, C)
@@ -167,10 +170,10 @@ class CrossAttentionBlock(nn.Module):
         tok = ops.linear(o, ca.out_proj.weight, ca.out_proj.bias, residual=tok, alpha=0.8)
         # feed-forward, no norm (unet.py:247-251)
         if _FUSED_FFN:
-            tok = ops.ffn(tok, self.ffn[0].weight, self.ffn[0].bias, self.ffn[3].weight, self.ffn[3].bias, 0.6, p, seeds[2], seeds[3])
+            tok = ops.ffn(tok, self.ffn[0].weight, self.ffn[0].bias, self.ffn[3].weight, self.ffn[3].bias, 0.6, p, seeds[2], seeds[3], out=out)
         else:                                          # two generic nodes (PSG_FFN_FUSE=0: A/B and debugging)
             h = ops.linear(tok, self.ffn[0].weight, self.ffn[0].bias, act=ACT_GELU, drop_p=p, seed=seeds[2])
-            tok = ops.linear(h, self.ffn[3].weight, self.ffn[3].bias, residual=tok, alpha=0.6, drop_p=p, seed=seeds[3])
+            tok = ops.linear(h, self.ffn[3].weight, self.ffn[3].bias, residual=tok, alpha=0.6, drop_p=p, seed=seeds[3], out=out)
         return tok.reshape(B, H, W, C)
 
     def forward(self, x: torch.Tensor, text_emb: torch.Tensor) -> torch.Tensor:
@@ -190,9 +193,11 @@ class UNetBlock(nn.Module):
             self.attn_block = CrossAttentionBlock(out_channels, text_emb_dim, num_heads)
         self.compute_dtype = torch.float32
 
-    def nhwc(self, x, temb, pooled, text):
+    def nhwc(self, x, temb, pooled, text, out=None):
+        if not self.has_attention:
+            return self.res_block.nhwc(x, temb, pooled, out=out)
         x = self.res_block.nhwc(x, temb, pooled)
-        return self.attn_block.nhwc(x, text) if self.has_attention else x
+        return self.attn_block.nhwc(x, text, out=out)
 
     def forward(self, x, time_emb, text_emb, text_seq):
         dt = self.compute_dtype
@@ -275,22 +280,47 @@ class UNet(nn.Module):
         pooled, text = ops.text_pool(text_emb, dt)
         x = ops.conv2d(x, self.init_conv.weight, self.init_conv.bias)
         skips = []
+        slots = _CONCAT_SLOTS and all(len(getattr(self, f"dec_block{lvl}")) == 2 for lvl in range(4))
         for lvl in range(4):
             if lvl > 0:
                 ds = getattr(self, f"downsample{lvl}")
                 x = ops.conv2d(x, ds.weight, ds.bias, stride=2)
             for blk in getattr(self, f"enc_block{lvl}"):
                 x = blk.nhwc(x, temb, pooled, text)
-            skips.append(x)
-        x = self.middle_block.nhwc(x, temb, pooled, text)
-        for lvl in (3, 2, 1, 0):
-            skip = skips.pop()
-            for blk in getattr(self, f"dec_block{lvl}"):
-                x = blk.nhwc(torch.cat([x, skip], dim=-1), temb, pooled, text)   # same skip for both blocks (unet.py:480-504)
-            if lvl > 0:
-                up = getattr(self, f"upsample{lvl}")
-                x = ops.upsample_bilinear(x, up[0].size)
-                x = ops.conv2d(x, up[1].weight, up[1].bias)
+            if slots:
+                # the skip has three consumers (next stage, two decoder blocks): their gradients are summed in one pass
+                x, s0, s1 = ops.fan3(x)
+                skips.append((s0, s1))
+            else:
+                skips.append(x)
+        if not slots:
+            x = self.middle_block.nhwc(x, temb, pooled, text)
+            for lvl in (3, 2, 1, 0):
+                skip = skips.pop()
+                for blk in getattr(self, f"dec_block{lvl}"):
+                    x = blk.nhwc(torch.cat([x, skip], dim=-1), temb, pooled, text)   # same skip for both blocks (unet.py:480-504)
+                if lvl > 0:
+                    up = getattr(self, f"upsample{lvl}")
+                    x = ops.upsample_bilinear(x, up[0].size)
+                    x = ops.conv2d(x, up[1].weight, up[1].bias)
+        else:
+            # torch.cat([x, skip]) without the concat (unet.py:480-504; same skip for both blocks of a level): the skip half
+            # is copied into a [.., C1 + C2] buffer when that buffer is made, and the op that produces x writes it straight
+            # into the other half (ops.ConcatSlot / ops.OutSlot) - half the concat's traffic, no CatArrayBatchedCopy.
+            slot = ops.ConcatSlot(skips[-1][0], self.middle_block.res_block.out_channels)
+            x = self.middle_block.nhwc(x, temb, pooled, text, out=slot.out)
+            for lvl in (3, 2, 1, 0):
+                s0, s1 = skips.pop()
+                b0, b1 = getattr(self, f"dec_block{lvl}")
+                xc = slot.cat(x, s0)
+                slot = ops.ConcatSlot(s1, b0.res_block.out_channels)
+                x = b0.nhwc(xc, temb, pooled, text, out=slot.out)
+                x = b1.nhwc(slot.cat(x, s1), temb, pooled, text)
+                if lvl > 0:
+                    up = getattr(self, f"upsample{lvl}")
+                    x = ops.upsample_bilinear(x, up[0].size)
+                    slot = ops.ConcatSlot(skips[-1][0], up[1].out_channels)
+                    x = ops.conv2d(x, up[1].weight, up[1].bias, out=slot.out)
         gn, conv = self.final_conv[0], self.final_conv[2]
         x = ops.group_norm(x, gn.weight, gn.bias, gn.num_groups, gn.eps, silu=True)
         x = ops.conv2d(x, conv.weight, conv.bias)
