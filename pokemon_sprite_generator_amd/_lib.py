@@ -137,7 +137,14 @@ def init(device_index: int):
     return lib
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream_ptr():
+    """The current HIP stream of the current device as a C pointer (honours `with torch.cuda.stream(...)`).  The raw
+    accessor skips the Stream object `torch.cuda.current_stream()` builds: 8 us a call, ~1000 calls per train step."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
@@ -162,7 +169,8 @@ _ws = {}
 def workspace(nbytes: int, device):
     # one buffer per (device, stream): kernels on one stream run in order, so they can share scratch; a second
     # stream (ops: weight gradients overlapped with data gradients) gets its own
-    key = (device.index if device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(device).cuda_stream)
+    di = device.index if device.index is not None else torch.cuda.current_device()
+    key = (di, _raw_stream(di) if _raw_stream is not None else torch.cuda.current_stream(device).cuda_stream)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
