@@ -140,6 +140,14 @@ int psg_upsample_bilinear_bwd(const void* dy, int64_t lddy, void* dx, int64_t ld
 /* y = a + b (elementwise, strided rows); used for gradient fan-in of skip tensors. */
 int psg_add(const void* a, int64_t lda, const void* b, int64_t ldb, void* y, int64_t ldy, int64_t rows,
             int cols, int dtype, psg_stream_t stream);
+/* Dropout under hipGraph replay.  Every mask in this library is a stateless hash of (seed, element index); the seeds are
+ * launch arguments, so a captured train step would replay the SAME masks forever.  After psg_set_seed_source(p) every launch
+ * that draws a mask adds the 64-bit word at device address p to its seed when it RUNS (conv / Linear epilogues, attention,
+ * psg_dropout_apply, psg_epilogue_bwd - forward and backward of a step read the same value, so they still agree); the caller
+ * advances the word on the device between steps.  NULL (default) restores the plain seeds.  Process-wide (one process per
+ * GPU).  Reference: nn.Dropout / MultiheadAttention(dropout=) draw fresh masks every step (unet.py:160-187). */
+int psg_set_seed_source(const uint64_t* seed_dev);
+
 /* y = a (+ b (+ c)), b / c may be NULL (c needs b): row-strided [rows][cols] operands, 16-byte chunks (cols and row strides
  * multiples of 8 bf16 / 4 fp32), the fp32 sum rounded once.  One source: the strided copy of a skip tensor into its half of
  * the decoder's concat buffer (reference unet.py:480-504 `torch.cat([x, skip], dim=1)`: the x half is written there by

@@ -66,6 +66,7 @@ SIGNATURES = {
     "psg_upsample_bilinear_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64] + [c_int] * 7 + [c_void_p]),
     "psg_upsample_bilinear_bwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64] + [c_int] * 7 + [c_void_p]),
     "psg_add": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
+    "psg_set_seed_source": (c_int, [c_void_p]),
     "psg_sum_rows": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     "psg_groupnorm_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64] + [c_void_p] * 4 + [c_int] * 4 + [c_float, c_int, c_int, c_void_p, c_void_p]),
     "psg_groupnorm_fwd_workspace_bytes": (c_int64, [c_int, c_int]),

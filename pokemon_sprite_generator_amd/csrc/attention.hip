@@ -20,6 +20,7 @@ struct AttnP {
     int B, H, L, S, d;
     float scale;
     uint32_t drop_thresh; float drop_scale; uint64_t seed;
+    const uint64_t* seed_dev;
 };
 
 // dropout element index of P[bh][l][s]: each query row owns ceil(S/2) hash PAIRS (keys 2k, 2k+1 share one 32-bit hash),
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnP p) {
             const float inv = 1.0f / sum;
             for (int s = lane; s < p.S; s += 64) {
                 float pv = row[s] * inv;
-                if (p.drop_thresh && l < p.L) pv = drop_keep(p.seed, attn_idx(p, bh, l, s), p.drop_thresh) ? pv * p.drop_scale : 0.f;
+                if (p.drop_thresh && l < p.L) pv = drop_keep(eff_seed(p.seed, p.seed_dev), attn_idx(p, bh, l, s), p.drop_thresh) ? pv * p.drop_scale : 0.f;
                 row[s] = pv;
             }
             if (lane == 0 && l < p.L) p.lse[(int64_t)bh * p.L + l] = mx + __logf(sum);
@@ -183,8 +184,8 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(const AttnP p) {
         if (s < p.S) {
             float pa = __expf(s_a - lse_a), pb = __expf(s_b - lse_b);
             if (p.drop_thresh) {
-                dp_a = (la < p.L && drop_keep(p.seed, attn_idx(p, bh, la, s), p.drop_thresh)) ? dp_a * p.drop_scale : 0.f;
-                dp_b = (lb < p.L && drop_keep(p.seed, attn_idx(p, bh, lb, s), p.drop_thresh)) ? dp_b * p.drop_scale : 0.f;
+                dp_a = (la < p.L && drop_keep(eff_seed(p.seed, p.seed_dev), attn_idx(p, bh, la, s), p.drop_thresh)) ? dp_a * p.drop_scale : 0.f;
+                dp_b = (lb < p.L && drop_keep(eff_seed(p.seed, p.seed_dev), attn_idx(p, bh, lb, s), p.drop_thresh)) ? dp_b * p.drop_scale : 0.f;
             }
             Ss[qa * Sp + s] = la < p.L ? pa * (dp_a - del_a) : 0.f;
             Ss[qb * Sp + s] = lb < p.L ? pb * (dp_b - del_b) : 0.f;
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(const AttnP p) {
                 if (sa < p.S) {
                     float pr = __expf(s_a - lse), pd = pr;
                     if (p.drop_thresh) {
-                        const bool keep = drop_keep(p.seed, attn_idx(p, bh, l, sa), p.drop_thresh);
+                        const bool keep = drop_keep(eff_seed(p.seed, p.seed_dev), attn_idx(p, bh, l, sa), p.drop_thresh);
                         pd = keep ? pr * p.drop_scale : 0.f; dp_a = keep ? dp_a * p.drop_scale : 0.f;
                     }
                     pa = pd; da = pr * (dp_a - del);
@@ -277,7 +278,7 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(const AttnP p) {
                 if (sb < p.S) {
                     float pr = __expf(s_b - lse), pd = pr;
                     if (p.drop_thresh) {
-                        const bool keep = drop_keep(p.seed, attn_idx(p, bh, l, sb), p.drop_thresh);
+                        const bool keep = drop_keep(eff_seed(p.seed, p.seed_dev), attn_idx(p, bh, l, sb), p.drop_thresh);
                         pd = keep ? pr * p.drop_scale : 0.f; dp_b = keep ? dp_b * p.drop_scale : 0.f;
                     }
                     pb = pd; db = pr * (dp_b - del);
@@ -331,6 +332,7 @@ struct AttnMP {
     int B, H, L, S, d;
     float scale;
     uint32_t drop_thresh; float drop_scale; uint64_t seed;
+    const uint64_t* seed_dev;
 };
 int attn_mfma_applicable(int L, int S, int d, int dtype, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo);
 int attn_mfma_init_attrs();
@@ -346,6 +348,7 @@ struct AttnFP {
     int B, H, L, S, d;
     float scale;
     uint32_t drop_thresh; float drop_scale; uint64_t seed;
+    const uint64_t* seed_dev;
 };
 int attn_f32_applicable(int L, int S, int d, int dtype, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo);
 int attn_f32_init_attrs();
@@ -359,7 +362,7 @@ static AttnFP to_f32(const AttnP& a) {
     m.lse = a.lse; m.delta = a.delta;
     m.ldq = a.ldq; m.ldk = a.ldk; m.ldv = a.ldv; m.ldo = a.ldo; m.lddo = a.lddo; m.lddq = a.lddq; m.lddk = a.lddk; m.lddv = a.lddv;
     m.B = a.B; m.H = a.H; m.L = a.L; m.S = a.S; m.d = a.d; m.scale = a.scale;
-    m.drop_thresh = a.drop_thresh; m.drop_scale = a.drop_scale; m.seed = a.seed;
+    m.drop_thresh = a.drop_thresh; m.drop_scale = a.drop_scale; m.seed = a.seed; m.seed_dev = a.seed_dev;
     return m;
 }
 
@@ -370,7 +373,7 @@ static AttnMP to_mfma(const AttnP& a) {
     m.lse = a.lse; m.delta = a.delta;
     m.ldq = a.ldq; m.ldk = a.ldk; m.ldv = a.ldv; m.ldo = a.ldo; m.lddo = a.lddo; m.lddq = a.lddq; m.lddk = a.lddk; m.lddv = a.lddv;
     m.B = a.B; m.H = a.H; m.L = a.L; m.S = a.S; m.d = a.d; m.scale = a.scale;
-    m.drop_thresh = a.drop_thresh; m.drop_scale = a.drop_scale; m.seed = a.seed;
+    m.drop_thresh = a.drop_thresh; m.drop_scale = a.drop_scale; m.seed = a.seed; m.seed_dev = a.seed_dev;
     return m;
 }
 
@@ -416,7 +419,7 @@ int psg_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const v
     AttnP p = {};
     p.q = q; p.k = k; p.v = v; p.out = o; p.lse = lse; p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
     p.B = B; p.H = heads; p.L = L; p.S = S; p.d = d; p.scale = scale;
-    p.drop_thresh = drop_p > 0.f ? drop_thresh(drop_p) : 0u; p.drop_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f; p.seed = seed;
+    p.drop_thresh = drop_p > 0.f ? drop_thresh(drop_p) : 0u; p.drop_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f; p.seed = seed; p.seed_dev = seed_source();
     dim3 grid((L + AT_Q - 1) / AT_Q, B * heads);
     ProfScope prof(PROF_ATTN, 4.0 * (double)B * heads * L * S * d, (hipStream_t)stream);
     if (attn_mfma_applicable(L, S, d, dtype, ldq, ldk, ldv, ldo) && aligned16(q) && aligned16(k) && aligned16(v) && aligned8(o)) {
@@ -451,7 +454,7 @@ int psg_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const v
     p.dq = dq; p.dk = dk; p.dv = dv;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo; p.lddo = lddo; p.lddq = lddq; p.lddk = lddk; p.lddv = lddv;
     p.B = B; p.H = heads; p.L = L; p.S = S; p.d = d; p.scale = scale;
-    p.drop_thresh = drop_p > 0.f ? drop_thresh(drop_p) : 0u; p.drop_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f; p.seed = seed;
+    p.drop_thresh = drop_p > 0.f ? drop_thresh(drop_p) : 0u; p.drop_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f; p.seed = seed; p.seed_dev = seed_source();
     hipStream_t s = (hipStream_t)stream;
     const int64_t rows = (int64_t)B * heads * L;
     const int gdelta = (int)((rows + 3) / 4);

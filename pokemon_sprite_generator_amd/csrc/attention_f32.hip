@@ -25,6 +25,7 @@ struct AttnFP {
     int B, H, L, S, d;
     float scale;
     uint32_t drop_thresh; float drop_scale; uint64_t seed;
+    const uint64_t* seed_dev;
 };
 
 __device__ __forceinline__ int acc_row32(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256, 1) void attn_fwd_f32(const AttnFP p) {
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const int key = kt * 32 + acc_row32(r, fh);
-                    const uint32_t hh = drop_hash_pair(p.seed, prow + (uint32_t)(key >> 1));
+                    const uint32_t hh = drop_hash_pair(eff_seed(p.seed, p.seed_dev), prow + (uint32_t)(key >> 1));
                     st[r] = (lok && key < p.S && drop_keep_half(hh, 0, p.drop_thresh)) ? st[r] * p.drop_scale : 0.f;
                     st[r + 1] = (lok && key + 1 < p.S && drop_keep_half(hh, 1, p.drop_thresh)) ? st[r + 1] * p.drop_scale : 0.f;
                 }
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256, 1) void attn_dq_f32(const AttnFP p) {
                     const float pr = __expf(st[r] * p.scale - lse);
                     float dpr = dp[r];
                     if (p.drop_thresh) {
-                        const uint32_t hh = drop_hash_pair(p.seed, prow + (uint32_t)(key >> 1));
+                        const uint32_t hh = drop_hash_pair(eff_seed(p.seed, p.seed_dev), prow + (uint32_t)(key >> 1));
                         dpr = drop_keep_half(hh, key & 1, p.drop_thresh) ? dpr * p.drop_scale : 0.f;
                     }
                     ds = pr * (dpr - del) * p.scale;
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(256, 1) void attn_dkv_f32(const AttnFP p) {
                     float dpr = dp[r];
                     pv = pr;
                     if (p.drop_thresh) {
-                        const uint32_t hh = drop_hash_pair(p.seed, ((uint64_t)bh * p.L + l) * (uint64_t)((p.S + 1) >> 1) + (uint32_t)(key >> 1));
+                        const uint32_t hh = drop_hash_pair(eff_seed(p.seed, p.seed_dev), ((uint64_t)bh * p.L + l) * (uint64_t)((p.S + 1) >> 1) + (uint32_t)(key >> 1));
                         const bool keep = drop_keep_half(hh, key & 1, p.drop_thresh);
                         pv = keep ? pr * p.drop_scale : 0.f;
                         dpr = keep ? dpr * p.drop_scale : 0.f;

@@ -35,6 +35,7 @@ struct AttnMP {     // mirrored in attention.hip
     int B, H, L, S, d;
     float scale;
     uint32_t drop_thresh; float drop_scale; uint64_t seed;
+    const uint64_t* seed_dev;
 };
 
 typedef __attribute__((ext_vector_type(8))) short s16x8;
@@ -104,6 +105,7 @@ __global__ __launch_bounds__(256, (ND <= 5 ? 2 : 1)) void attn_fwd_mfma(const At
     char* Ks = smem;
     char* Vs = smem + Sp * STR;
     const int bh = blockIdx.x, b = bh / p.H, hd = bh - b * p.H;
+    const uint64_t seed = eff_seed(p.seed, p.drop_thresh ? p.seed_dev : nullptr);     // wave-uniform
     const int d = ND * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bf16_t* qg = p.q + (int64_t)b * p.L * p.ldq + hd * d;
@@ -161,7 +163,7 @@ __global__ __launch_bounds__(256, (ND <= 5 ? 2 : 1)) void attn_fwd_mfma(const At
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {          // registers r, r+1 hold keys 2k, 2k+1: one hash for both
                     const int key = kt * 32 + acc_row(r, fh);
-                    const uint32_t hh = drop_hash_pair(p.seed, prow + (uint32_t)(key >> 1));
+                    const uint32_t hh = drop_hash_pair(seed, prow + (uint32_t)(key >> 1));
                     st[r] = (lok && key < p.S && drop_keep_half(hh, 0, p.drop_thresh)) ? st[r] * p.drop_scale : 0.f;
                     st[r + 1] = (lok && key + 1 < p.S && drop_keep_half(hh, 1, p.drop_thresh)) ? st[r + 1] * p.drop_scale : 0.f;
                 }
@@ -210,6 +212,7 @@ __global__ __launch_bounds__(256, (ND <= 5 ? 2 : 1)) void attn_dq_mfma(const Att
     char* Ks = smem;
     char* Vs = smem + Sp * STR;
     const int bh = blockIdx.x, b = bh / p.H, hd = bh - b * p.H;
+    const uint64_t seed = eff_seed(p.seed, p.drop_thresh ? p.seed_dev : nullptr);     // wave-uniform
     const int d = ND * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bf16_t* qg = p.q + (int64_t)b * p.L * p.ldq + hd * d;
@@ -255,7 +258,7 @@ __global__ __launch_bounds__(256, (ND <= 5 ? 2 : 1)) void attn_dq_mfma(const Att
         for (int t = 0; t < NDT; ++t)
 #pragma unroll
             for (int e = 0; e < 16; ++e) dacc[t][e] = 0.f;
-        const DropRow dr = drop_row(p.seed, ((uint64_t)bh * p.L + l) * (uint64_t)((p.S + 1) >> 1));
+        const DropRow dr = drop_row(seed, ((uint64_t)bh * p.L + l) * (uint64_t)((p.S + 1) >> 1));
         const uint32_t t16 = p.drop_thresh >> 16;
         for (int kt = 0; kt < nkt; ++kt) {
             f32x16 st, dp;
@@ -324,6 +327,7 @@ __global__ __launch_bounds__(256, (ND <= 5 ? 2 : 1)) void attn_dkv_mfma(const At
     char* KVw = Gs + Lp * STR + 32;                          // (ND > 5) per wave: K tile [32][STR] | V tile [32][STR]
     // lse[l] / delta[l] live in the 16-byte pad slot of row l of the Q image (bytes 2d .. 2d+7)
     const int bh = blockIdx.x, b = bh / p.H, hd = bh - b * p.H;
+    const uint64_t seed = eff_seed(p.seed, p.drop_thresh ? p.seed_dev : nullptr);     // wave-uniform
     const int d = ND * 16;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bf16_t* qg = p.q + (int64_t)b * p.L * p.ldq + hd * d;
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(256, (ND <= 5 ? 2 : 1)) void attn_dkv_mfma(const At
                     float dpr = dp[r];
                     pv = pr;
                     if (p.drop_thresh) {
-                        const uint32_t hh = drop_hash_pair(p.seed, ((uint64_t)bh * p.L + l) * (uint64_t)((p.S + 1) >> 1) + (uint32_t)(key >> 1));
+                        const uint32_t hh = drop_hash_pair(seed, ((uint64_t)bh * p.L + l) * (uint64_t)((p.S + 1) >> 1) + (uint32_t)(key >> 1));
                         const bool keep = drop_keep_half(hh, key & 1, p.drop_thresh);
                         pv = keep ? pr * p.drop_scale : 0.f;
                         dpr = keep ? dpr * p.drop_scale : 0.f;

@@ -135,6 +135,7 @@ int psg_conv_fwd(const psg_conv_desc* d, psg_stream_t stream) {
     p.drop_thresh = d->drop_p > 0.f ? drop_thresh(d->drop_p) : 0u;
     p.drop_scale = d->drop_p > 0.f ? 1.0f / (1.0f - d->drop_p) : 1.0f;
     p.drop_seed = d->drop_seed;
+    p.seed_dev = seed_source();
     p.mtiles = p.ntiles = 0;
     {
         const int64_t esz = d->dtype == PSG_BF16 ? 2 : 4;

@@ -36,6 +36,7 @@ struct ConvP {
     int epi_lds;                   // bf16: stage the output tile through LDS and store whole 16-byte row chunks
     int epi_generic;               // PSG_EPI_KINDS=0: run-time epilogue form for every launch (A/B of the per-kind copies)
     uint32_t drop_thresh; float drop_scale; uint64_t drop_seed;
+    const uint64_t* seed_dev;      // optional device word added to drop_seed (psg_set_seed_source): per-step masks under hipGraph replay
     uint32_t x_bytes, w_bytes;     // extents for the bounds-checked buffer loads
     // MODE 3 (one parity class of a stride-2 data gradient): result pixels (sub_h0 + 2i, sub_w0 + 2j), i < sub_nH,
     // j < sub_nW; only the ntap filter taps that reach them: source pixel (i + tap_dh, j + tap_dw), weight tap tap_wi
@@ -90,7 +91,7 @@ __device__ __forceinline__ void conv_out_row(const ConvP& p, int mt, int& m, int
 // value(s) of the fused epilogue for 4 consecutive channels: `v` becomes the output value; returns in `pre` what the
 // `preact` buffer receives (the pre-activation u, or with PSG_CONV_SAVE_DACT the epilogue's derivative)
 template <typename T>
-__device__ __forceinline__ void conv_value(const ConvP& p, int m, int n, f32x4& v, f32x4& pre, f32x4 bias4, f32x4 ra4, f32x4 aux4) {
+__device__ __forceinline__ void conv_value(const ConvP& p, int m, int n, f32x4& v, f32x4& pre, f32x4 bias4, f32x4 ra4, f32x4 aux4, uint64_t dseed) {
     // aux4: the residual, or (backward form, dact_u set - the two are mutually exclusive) the saved pre-activation u /
     // the saved epilogue derivative
     constexpr bool FAST = sizeof(T) == 2;                  // bf16 compute: bf16-grade GELU (exact fp32 path keeps erff)
@@ -116,7 +117,7 @@ __device__ __forceinline__ void conv_value(const ConvP& p, int m, int n, f32x4& 
     if (p.drop_thresh) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const bool keep = drop_keep(p.drop_seed, (uint64_t)m * p.N + n + e, p.drop_thresh);
+            const bool keep = drop_keep(dseed, (uint64_t)m * p.N + n + e, p.drop_thresh);
             v[e] = keep ? v[e] * p.drop_scale : 0.f;
             d[e] = keep ? d[e] * p.drop_scale : 0.f;
         }
@@ -136,8 +137,8 @@ enum { EK_PLAIN = 0, EK_DROP = 1, EK_GELU = 2, EK_GELU_DROP = 3, EK_DMUL = 4, EK
 // AUX_LATER: stop before the aux operand (the residual, or EK_DMUL's saved derivative) enters - conv_aux_k applies it
 // later to the same fp32 value, so the result is the one-step form's bit for bit.
 template <typename T, int EK, bool AUX_LATER = false>
-__device__ __forceinline__ void conv_value_k(const ConvP& p, int m, int n, f32x4& v, f32x4& pre, f32x4 bias4, f32x4 ra4, f32x4 aux4) {
-    if constexpr (EK == EK_GENERIC) { conv_value<T>(p, m, n, v, pre, bias4, ra4, aux4); return; }
+__device__ __forceinline__ void conv_value_k(const ConvP& p, int m, int n, f32x4& v, f32x4& pre, f32x4 bias4, f32x4 ra4, f32x4 aux4, uint64_t dseed) {
+    if constexpr (EK == EK_GENERIC) { conv_value<T>(p, m, n, v, pre, bias4, ra4, aux4, dseed); return; }
     else {
         v += bias4 + ra4;
         pre = v;
@@ -156,7 +157,7 @@ __device__ __forceinline__ void conv_value_k(const ConvP& p, int m, int n, f32x4
         if constexpr (EK == EK_DROP || EK == EK_GELU_DROP) {
             // n is a multiple of 4 and N of 8: the 4 elements are the pairs (idx>>1, idx>>1 + 1) of drop_keep
             const uint64_t pair = ((uint64_t)m * p.N + n) >> 1;
-            const uint32_t h0 = drop_hash_pair(p.drop_seed, pair), h1 = drop_hash_pair(p.drop_seed, pair + 1);
+            const uint32_t h0 = drop_hash_pair(dseed, pair), h1 = drop_hash_pair(dseed, pair + 1);
             const bool k[4] = {drop_keep_half(h0, 0, p.drop_thresh), drop_keep_half(h0, 1, p.drop_thresh),
                                drop_keep_half(h1, 0, p.drop_thresh), drop_keep_half(h1, 1, p.drop_thresh)};
 #pragma unroll
@@ -178,11 +179,11 @@ __device__ __forceinline__ float conv_aux_k(const ConvP& p, float v, float aux) 
 }
 
 template <typename T>
-__device__ __forceinline__ void conv_emit(const ConvP& p, int m, int n, f32x4 v, f32x4 bias4, f32x4 ra4, f32x4 aux4) {
+__device__ __forceinline__ void conv_emit(const ConvP& p, int m, int n, f32x4 v, f32x4 bias4, f32x4 ra4, f32x4 aux4, uint64_t dseed) {
     T* yg = reinterpret_cast<T*>(p.y);
     T* preg = reinterpret_cast<T*>(p.preact);
     f32x4 pre;
-    conv_value<T>(p, m, n, v, pre, bias4, ra4, aux4);
+    conv_value<T>(p, m, n, v, pre, bias4, ra4, aux4, dseed);
     if (preg) store4<T>(preg + (int64_t)m * p.ldpre + n, pre);
     store4<T>(yg + (int64_t)m * p.ldy + n, v);
 }
@@ -493,6 +494,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
     __syncthreads();                       // every wave is done with the tile buffers: the epilogue reuses them
 
     // ---- fused epilogue: phase 1 loads every bias / residual operand of the tile, phase 2 computes and stores ----
+    const uint64_t dseed = p.drop_seed + ((p.drop_thresh && p.seed_dev) ? *p.seed_dev : 0ull);     // wave-uniform
     if constexpr (FT16) {
         if (p.epi_lds) {
             // LDS-staged stores.  In the accumulator layout a lane owns 4 channels of one pixel, so a store instruction
@@ -537,7 +539,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
                             const bf16x4 rr = *reinterpret_cast<const bf16x4*>(cell);
                             r4[0] = (float)rr[0]; r4[1] = (float)rr[1]; r4[2] = (float)rr[2]; r4[3] = (float)rr[3];
                         }
-                        conv_value_k<T, EK>(p, rows[j], n, v, pre, bias4[i], ra4[i], r4);
+                        conv_value_k<T, EK>(p, rows[j], n, v, pre, bias4[i], ra4[i], r4, dseed);
                         const f32x4 o = PASS == 0 ? pre : v;
                         bf16x4 ob = {(bf16_t)o[0], (bf16_t)o[1], (bf16_t)o[2], (bf16_t)o[3]};
                         *reinterpret_cast<bf16x4*>(cell) = ob;
@@ -583,7 +585,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
                             const int n = n0 + wn * WN + i * 16 + 4 * kq;
                             f32x4 v = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                             f32x4 pre;
-                            conv_value_k<T, EK>(p, rows[j], n, v, pre, bias4[i], ra4[i], zero4);
+                            conv_value_k<T, EK>(p, rows[j], n, v, pre, bias4[i], ra4[i], zero4, dseed);
                             const int off = (jj * 16 + l16) * PITCH + (i * 16 + 4 * kq) * 2;
                             bf16x4 pb = {(bf16_t)pre[0], (bf16_t)pre[1], (bf16_t)pre[2], (bf16_t)pre[3]};
                             bf16x4 vb = {(bf16_t)v[0], (bf16_t)v[1], (bf16_t)v[2], (bf16_t)v[3]};
@@ -636,7 +638,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
                             const int n = n0 + wn * WN + i * 16 + 4 * kq;
                             f32x4 v = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                             f32x4 pre;
-                            conv_value_k<T, EK, true>(p, rows[j], n, v, pre, bias4[i], ra4[i], zero4);
+                            conv_value_k<T, EK, true>(p, rows[j], n, v, pre, bias4[i], ra4[i], zero4, dseed);
                             *reinterpret_cast<f32x4*>(reg + (jj * 16 + l16) * PITCHF + (i * 16 + 4 * kq) * 4) = v;
                         }
                         __builtin_amdgcn_sched_barrier(0);
@@ -708,7 +710,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
                 f32x4 v = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                 f32x4 r4 = zero4;
                 if (resg) { r4[0] = (float)res_raw[i][j][0]; r4[1] = (float)res_raw[i][j][1]; r4[2] = (float)res_raw[i][j][2]; r4[3] = (float)res_raw[i][j][3]; }
-                conv_emit<T>(p, rows[j], n, v, bias4[i], ra4[i], r4);
+                conv_emit<T>(p, rows[j], n, v, bias4[i], ra4[i], r4, dseed);
             }
         }
     } else {
@@ -733,7 +735,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
                     const int n = n0 + wn * WN + i * 32 + 8 * g + 4 * fh;
                     if (n >= p.N) continue;
                     f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
-                    conv_emit<T>(p, m, n, v, b4[g], a4[g], r4[g]);
+                    conv_emit<T>(p, m, n, v, b4[g], a4[g], r4[g], dseed);
                 }
             }
         }

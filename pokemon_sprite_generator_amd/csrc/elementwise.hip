@@ -4,6 +4,11 @@
 
 namespace psg {
 
+// psg_set_seed_source: one word per process (one process per GPU), read by every launch that draws a dropout mask
+const uint64_t* g_seed_source = nullptr;
+const uint64_t* seed_source() { return g_seed_source; }
+
+
 static thread_local char g_err[512] = "";
 
 int set_error(int code, const char* fmt, ...) {
@@ -335,7 +340,8 @@ __global__ void sum_rows_kernel(const T* __restrict__ a, int64_t lda, const T* _
 
 template <typename T>
 __global__ void dropout_apply_kernel(const T* __restrict__ x, int64_t ldx, T* __restrict__ y, int64_t ldy,
-                                     int64_t rows, int cols, uint32_t thresh, uint64_t seed, float scale) {
+                                     int64_t rows, int cols, uint32_t thresh, uint64_t seed0, float scale, const uint64_t* seed_dev) {
+    const uint64_t seed = eff_seed(seed0, seed_dev);
     const int c4n = cols >> 2;
     const int64_t n = rows * c4n;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -351,7 +357,8 @@ __global__ void dropout_apply_kernel(const T* __restrict__ x, int64_t ldx, T* __
 template <typename T>
 __global__ void epilogue_bwd_kernel(const T* __restrict__ dy, int64_t lddy, const T* __restrict__ u, int64_t ldu,
                                     T* __restrict__ g, int64_t ldg, int64_t rows, int cols, int act, float alpha,
-                                    uint32_t thresh, float drop_scale, uint64_t seed) {
+                                    uint32_t thresh, float drop_scale, uint64_t seed0, const uint64_t* seed_dev) {
+    const uint64_t seed = eff_seed(seed0, thresh ? seed_dev : nullptr);
     const int c4n = cols >> 2;
     const int64_t n = rows * c4n;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -906,6 +913,11 @@ int psg_add(const void* a, int64_t lda, const void* b, int64_t ldb, void* y, int
     return PSG_OK;
 }
 
+int psg_set_seed_source(const uint64_t* seed_dev) {
+    psg::g_seed_source = seed_dev;
+    return PSG_OK;
+}
+
 int psg_sum_rows(const void* a, int64_t lda, const void* b, int64_t ldb, const void* c, int64_t ldc, void* y, int64_t ldy,
                  int64_t rows, int cols, int dtype, psg_stream_t stream) {
     PSG_REQUIRE(a && y && (b || !c), PSG_ERR_ARG, "sum_rows: null pointer (c needs b)");
@@ -929,8 +941,8 @@ int psg_dropout_apply(const void* x, int64_t ldx, void* y, int64_t ldy, int64_t 
     const int g = grid_for(rows * (cols / 4), 256, 8192);
     const uint32_t th = drop_thresh(p);
     DISPATCH_DTYPE(dtype,
-        hipLaunchKernelGGL(dropout_apply_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (float*)y, ldy, rows, cols, th, seed, scale),
-        hipLaunchKernelGGL(dropout_apply_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, rows, cols, th, seed, scale));
+        hipLaunchKernelGGL(dropout_apply_kernel<float>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const float*)x, ldx, (float*)y, ldy, rows, cols, th, seed, scale, seed_source()),
+        hipLaunchKernelGGL(dropout_apply_kernel<bf16_t>, dim3(g), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, rows, cols, th, seed, scale, seed_source()));
     PSG_LAUNCH_CHECK("dropout_apply");
     return PSG_OK;
 }
@@ -944,8 +956,8 @@ int psg_epilogue_bwd(const void* dy, int64_t lddy, const void* u, int64_t ldu, v
     const uint32_t th = drop_p > 0.f ? drop_thresh(drop_p) : 0u;
     const float ds = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     DISPATCH_DTYPE(dtype,
-        hipLaunchKernelGGL(epilogue_bwd_kernel<float>, dim3(gr), dim3(256), 0, (hipStream_t)stream, (const float*)dy, lddy, (const float*)u, ldu, (float*)g, ldg, rows, cols, act, alpha, th, ds, seed),
-        hipLaunchKernelGGL(epilogue_bwd_kernel<bf16_t>, dim3(gr), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, lddy, (const bf16_t*)u, ldu, (bf16_t*)g, ldg, rows, cols, act, alpha, th, ds, seed));
+        hipLaunchKernelGGL(epilogue_bwd_kernel<float>, dim3(gr), dim3(256), 0, (hipStream_t)stream, (const float*)dy, lddy, (const float*)u, ldu, (float*)g, ldg, rows, cols, act, alpha, th, ds, seed, seed_source()),
+        hipLaunchKernelGGL(epilogue_bwd_kernel<bf16_t>, dim3(gr), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)dy, lddy, (const bf16_t*)u, ldu, (bf16_t*)g, ldg, rows, cols, act, alpha, th, ds, seed, seed_source()));
     PSG_LAUNCH_CHECK("epilogue_bwd");
     return PSG_OK;
 }

@@ -182,6 +182,12 @@ __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t 
     return drop_keep_half(drop_hash_pair(seed, idx >> 1), (int)(idx & 1), thresh);
 }
 // (attention_mfma.hip pairs the keys 2k, 2k+1 of a query row: pair = row * ceil(S/2) + (key >> 1))
+// Optional device word added to every dropout seed of a launch (psg_set_seed_source): the seeds themselves are launch
+// arguments, frozen when a train step is captured into a hipGraph - the word, advanced on the device between replays,
+// keeps the masks changing from step to step.  NULL (the default): seeds are used as passed.
+const uint64_t* seed_source();
+static __device__ __forceinline__ uint64_t eff_seed(uint64_t seed, const uint64_t* dev) { return seed + (dev ? *dev : 0ull); }
+
 static inline uint32_t drop_thresh(float p) {
     double t = (double)p * 4294967296.0;
     if (t < 0) t = 0;

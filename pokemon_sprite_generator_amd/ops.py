@@ -382,6 +382,38 @@ def _param_grad(param, compute):
 # ---------------------------------------------------------------------------
 # producing into a slice of a larger buffer (the decoder's concat) and the skip tensors' gradient fan-in
 # ---------------------------------------------------------------------------
+class SeedSource:
+    """The device word every dropout-drawing launch adds to its seed (psg_set_seed_source).  Seeds are launch arguments: a
+    train step captured into a hipGraph would replay the same masks forever; with the source enabled the per-site seeds stay
+    fixed from step to step (unet._SeedStream restarts its counter each step) and this word, advanced ON THE DEVICE at the end
+    of every step, is what changes - eager steps and graph replays then draw identical masks."""
+    _t = None
+    _STEP = -7046029254386353131            # 0x9E3779B97F4A7C15 as int64 (wraps)
+
+    @classmethod
+    def enabled(cls):
+        return cls._t is not None
+
+    @classmethod
+    def enable(cls, device):
+        if cls._t is None:
+            lib = _lib.init(device.index if device.index is not None else torch.cuda.current_device())
+            cls._t = torch.zeros(1, dtype=torch.int64, device=device)
+            check(lib.psg_set_seed_source(ptr(cls._t)), "psg_set_seed_source")
+        return cls._t
+
+    @classmethod
+    def disable(cls):
+        if cls._t is not None:
+            check(_lib.load().psg_set_seed_source(None), "psg_set_seed_source")
+            cls._t = None
+
+    @classmethod
+    def advance(cls):
+        if cls._t is not None:
+            cls._t.add_(cls._STEP)
+
+
 class OutSlot:
     """Where an op should produce its result: a row-strided view (same shape as the result) of a larger buffer.  A plain
     Python object on purpose - handed to an autograd Function as a tensor it would count as an INPUT returned as an output."""

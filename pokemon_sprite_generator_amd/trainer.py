@@ -30,6 +30,7 @@ from typing import Any, Dict, Optional
 import torch
 
 from . import _lib
+from . import ops as ops_mod
 from ._lib import FLAG_INPUT_BAD, FLAG_LOSS_BAD, FLAG_PRED_BAD, FLAG_SKIP_MASK, check, ptr, stream_ptr
 from .ddp import BucketedAllReduce, ShardedLoader, dist_info
 from .optim import FusedAdamW, GradArena, ParamArena
@@ -119,6 +120,9 @@ class DiffusionStepper:
         untouched."""
         if not self.unet.training:             # (module.train() walks all ~390 submodules: 1.6 ms of host time per call)
             self.unet.train()
+        if ops_mod.SeedSource.enabled():       # fixed per-site seeds + a device word that changes per step (graph replay)
+            from .unet import _SeedStream
+            _SeedStream.counter = 0
         if noise is None:
             noise = torch.randn_like(latents)
         self.flag.zero_()
@@ -146,7 +150,21 @@ class DiffusionStepper:
             self.host_steps += 1
             from .ops import WeightCache
             WeightCache.invalidate()
+        ops_mod.SeedSource.advance()
         return {"loss": loss.clone(), "grad_norm": normsq.sqrt(), "nan_flag": self.flag.clone()}
+
+    def capture_train_step(self, latents, text_emb, t, warmup=2):
+        """hipGraph of one whole train step (add_noise .. AdamW, ~1200 launches) for fixed shapes: returns a `GraphedTrainStep`
+        whose `run(latents, text_emb, t)` copies the batch into the captured buffers and replays.  The step has no host
+        reads (flags, step count and schedule live on the device) and its dropout masks keep changing between replays
+        through `ops.SeedSource`; noise is drawn inside the graph (torch's graph-safe generator).  `warmup` eager steps run
+        first ON THE GIVEN BATCH (they train); capture itself executes nothing.  Single process only (no gradient
+        all-reduce inside the graph).  23 ms of launches per step become one replay: the step is GPU-bound at any batch."""
+        if self.reducer is not None:
+            raise NotImplementedError("capture_train_step: data-parallel steps are not captured")
+        if not isinstance(self.optimizer, FusedAdamW):
+            raise NotImplementedError("capture_train_step needs the fused optimizer (device-side step count)")
+        return GraphedTrainStep(self, latents, text_emb, t, warmup)
 
     def steps_done(self) -> int:
         """Optimizer steps that really happened (host sync for the fused optimizer)."""
@@ -189,6 +207,40 @@ class DiffusionStepper:
     def sampler(self, text_emb, num_samples, fast_sampling=True, noise_fn=None, latent_dim=8, hw=27, use_graph=None, max_steps=None):
         """The same chain, one `step()` at a time (bench.py times single denoising steps)."""
         return SamplerRun(self, text_emb, num_samples, fast_sampling, noise_fn, latent_dim, hw, use_graph, max_steps)
+
+
+class GraphedTrainStep:
+    """See DiffusionStepper.capture_train_step."""
+
+    def __init__(self, stepper, latents, text_emb, t, warmup):
+        from .ops import SeedSource, WeightCache
+        self.stepper = stepper
+        dev = stepper.device
+        SeedSource.enable(dev)
+        self.lat, self.txt, self.t = latents.detach().clone(), text_emb.detach().clone(), t.detach().clone()
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                stepper.train_step(self.lat, self.txt, self.t)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out = stepper.train_step(self.lat, self.txt, self.t)
+        WeightCache.invalidate()
+
+    def run(self, latents=None, text_emb=None, t=None):
+        from .ops import WeightCache
+        if latents is not None:
+            self.lat.copy_(latents)
+        if text_emb is not None:
+            self.txt.copy_(text_emb)
+        if t is not None:
+            self.t.copy_(t)
+        self.graph.replay()
+        WeightCache.invalidate()          # the replay moved the weights: entries prepared by eager code are stale
+        return self.out
 
 
 class SamplerRun:

@@ -213,3 +213,47 @@ def test_stepper_overfits_a_fixed_batch(psg):
     assert float(l1.item()) < 0.1, float(l1.item())
     assert st.steps_done() == 1500
     st.close()
+
+
+def test_graphed_train_step_equals_eager(psg):
+    """The whole train step (add_noise .. AdamW) captured into a hipGraph: replays must leave EXACTLY the parameters eager steps
+    leave - same dropout masks too, which is what `ops.SeedSource` is for (seeds are launch arguments, frozen in a graph; the
+    device word they are added to advances on the device every step) - and consecutive replays must not repeat a mask."""
+    from pokemon_sprite_generator_amd import ops
+    dev = torch.device(DEV, 0)
+    B = 4
+
+    def make():
+        torch.manual_seed(0)
+        return psg.DiffusionStepper(psg.UNet(compute_dtype=torch.bfloat16).to(dev), psg.NoiseScheduler(), distributed=False)
+
+    g = torch.Generator(device=dev).manual_seed(1)
+    lat = torch.randn(B, 8, 27, 27, device=dev, generator=g)
+    txt = torch.randn(B, 32, 256, device=dev, generator=g)
+    t = torch.randint(0, 1000, (B,), device=dev, generator=g)
+    try:
+        word = ops.SeedSource.enable(dev)
+        word.zero_()
+        a = make()
+        torch.manual_seed(5)
+        for _ in range(4):
+            oa = a.train_step(lat, txt, t)
+        torch.cuda.synchronize()
+        pa, la, wa = a.params.flat.clone(), float(oa["loss"].item()), int(word.item())
+        a.close()
+        word.zero_()
+        b = make()
+        torch.manual_seed(5)
+        gs = b.capture_train_step(lat, txt, t, warmup=2)          # 2 eager steps, then the capture (executes nothing)
+        losses = [float(gs.run(lat, txt, t)["loss"].item()) for _ in range(2)]
+        torch.cuda.synchronize()
+        assert b.steps_done() == 4 and int(word.item()) == wa
+        assert torch.equal(b.params.flat, pa), "graph replays must take the eager steps bit for bit"
+        assert losses[-1] == la
+        assert losses[0] != losses[1]                              # fresh noise and fresh masks per replay
+        # eager code after replays sees the replayed weights (prepared-weight cache invalidated by run())
+        l_eval, _ = b.eval_loss(lat, txt, t, noise=torch.zeros_like(lat))
+        assert math.isfinite(float(l_eval.item()))
+        b.close()
+    finally:
+        ops.SeedSource.disable()
