@@ -29,7 +29,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FWD_GFLOP_PER_SAMPLE = 70.83           # FlopCounterMode on the reference, 2*MAC
+# Forward FLOPs per sample, 2*MAC: FlopCounterMode on the reference in TRAIN mode (conv 59.10 + addmm 8.53 + mm 9.28 + bmm
+# 0.56).  SURVEY.md §8(d)'s 70.83 was counted in eval / no_grad, where torch's fused MHA fast path hides the attention
+# projections from the counter; the arithmetic is the same in both modes.
+FWD_GFLOP_PER_SAMPLE = 77.46
 FWD_BWD_GFLOP_PER_SAMPLE = 232.12
 PEAK_BF16 = 2.5e15                      # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_F32 = 157.3e12                     # fp32 matrix (= vector) rate
@@ -170,26 +173,57 @@ def _free_port():
     return p
 
 
-def launch_ranks(n, argv):
+def launch_ranks(n, argv, rehearse=False):
     """Parent of a `python bench.py --gpus N` run: start one worker per GPU and relay rank 0's JSON line.  This process
-    makes no HIP / torch.cuda call (a process that initialised the GPU must not exec or fork workers on this platform)."""
+    makes no HIP / torch.cuda call (a process that initialised the GPU must not exec or fork workers on this platform).
+    Ranks > 0 write stdout + stderr to a scratch file each; when any rank fails its tail is relayed on stderr (a rank-1
+    failure used to vanish into DEVNULL).  `rehearse`: every worker gets LOCAL_RANK 0 (one GPU, gloo transport)."""
+    import tempfile
     port = _free_port()
-    procs = []
+    procs, logs = [], []
+    tmp = tempfile.mkdtemp(prefix="psg_bench_")
     for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(0 if rehearse else r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), PSG_BENCH_WORKER="1")
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        out = subprocess.PIPE if r == 0 else subprocess.DEVNULL
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=out))
+        if r == 0:
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=subprocess.PIPE))
+            logs.append(None)
+        else:
+            f = open(os.path.join(tmp, f"rank{r}.log"), "wb")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=f, stderr=subprocess.STDOUT))
+            logs.append(f)
     try:
         line, _ = procs[0].communicate(timeout=float(os.environ.get("PSG_BENCH_TIMEOUT", "1700")))
         codes = [procs[0].returncode] + [p.wait(timeout=120) for p in procs[1:]]
     except subprocess.TimeoutExpired:           # a rank hung (e.g. in the rendezvous): stop exactly the processes started here
+        codes = []
         for p in procs:
             if p.poll() is None:
                 p.kill()
+                codes.append(124)
+            else:
+                codes.append(p.returncode)          # (a rank that had already died keeps its own exit code)
         sys.stderr.write("bench.py: a rank did not finish in time; workers killed\n")
-        return 124
+        line = b""
+    for r, f in enumerate(logs):
+        if f is None:
+            continue
+        f.close()
+        if any(codes):
+            try:
+                tail = open(f.name, "rb").read()[-4000:].decode(errors="replace")
+            except OSError:
+                tail = ""
+            sys.stderr.write(f"---- bench.py rank {r} (exit {codes[r]}) ----\n{tail}\n")
+        try:
+            os.unlink(f.name)
+        except OSError:
+            pass
+    try:
+        os.rmdir(tmp)
+    except OSError:
+        pass
     sys.stdout.write(line.decode() if line else "")
     sys.stdout.flush()
     return max(abs(c) for c in codes)
@@ -209,6 +243,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip the HIP-event roofline leg")
     ap.add_argument("--profile-steps", type=int, default=3, help="steps of the exclusive-kernel roofline leg")
+    ap.add_argument("--rehearse", action="store_true", help="multi-rank plumbing check on ONE GPU: the N workers all use cuda:0 and meet "
+                                                            "over gloo (default batch 8, 2 steps); everything else - launch_ranks, the "
+                                                            "rendezvous, the bucketed all-reduce of the full 640 M-gradient arena, the "
+                                                            "max-over-ranks timing, the JSON line - is the production path")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] / configs[4] legs of the default run")
     ap.add_argument("--dry-run", action="store_true", help="rendezvous check only: the ranks meet over gloo on the CPU, all-reduce a 1 "
                                                            "and rank 0 prints the world size (no GPU; tests/test_bench_cpu.py)")
     args = ap.parse_args()
@@ -217,7 +256,7 @@ def main():
     if args.gpus > 1 and world_env != args.gpus:
         if os.environ.get("PSG_BENCH_WORKER"):
             raise SystemExit(f"worker started with WORLD_SIZE={world_env}, expected {args.gpus}")
-        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:], rehearse=args.rehearse))
     run_worker(args)
 
 
@@ -227,6 +266,9 @@ def run_worker(args):
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1")) if args.gpus > 1 else 1
     if args.dry_run:
+        if os.environ.get("PSG_BENCH_FAIL_RANK") == str(rank):          # (tests/test_bench_cpu.py: a rank that dies before the rendezvous)
+            print(f"rank {rank}: injected failure", flush=True)
+            sys.exit(3)
         one = torch.ones(1)
         if world > 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -238,12 +280,17 @@ def run_worker(args):
         return
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    nccl_world = 1
+    nccl_world, backend = 1, None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)   # nccl == RCCL on ROCm
+        if args.rehearse:                                # one GPU, N processes: gloo moves the buckets through the host
+            backend = "gloo"
+            torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            backend = "nccl"                             # nccl == RCCL on ROCm
+            torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         probe = torch.ones(1, device=dev)
-        torch.distributed.all_reduce(probe)            # an RCCL collective really ran: its sum IS the number of ranks
+        torch.distributed.all_reduce(probe)              # a collective really ran: its sum IS the number of ranks
         nccl_world = int(round(float(probe.item())))
 
     import pokemon_sprite_generator_amd as psg
@@ -253,99 +300,169 @@ def run_worker(args):
     fwd_bwd_only = (not sample_mode) and args.config == "fwd_bwd_fp32_bs64"
     dtype_name = args.dtype or ("fp32" if fwd_bwd_only else "bf16")
     dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
-    B = args.batch or (64 if (sample_mode or fwd_bwd_only) else 256)
-    steps = args.steps if args.steps is not None else (50 if sample_mode else 10)
-    warmup = args.warmup if args.warmup is not None else (5 if sample_mode else 3)
+    B = args.batch or (8 if args.rehearse else (64 if (sample_mode or fwd_bwd_only) else 256))
+    steps = args.steps if args.steps is not None else (2 if args.rehearse else (50 if sample_mode else 10))
+    warmup = args.warmup if args.warmup is not None else (1 if args.rehearse else (5 if sample_mode else 3))
     torch.manual_seed(1234)                      # (replicas are made equal by the stepper's rank-0 broadcast, not by this)
     unet = psg.UNet(latent_dim=8, text_dim=256, time_emb_dim=128, num_heads=8, compute_dtype=dtype).to(dev)
     stepper = psg.DiffusionStepper(unet, psg.NoiseScheduler(), lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01, eps=1e-6,
                                    max_grad_norm=1.0, distributed=(world > 1),
                                    grad_bucket_dtype=torch.bfloat16 if args.grad_bucket_dtype == "bf16" else torch.float32)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)          # every rank draws its own shard
-    latents = torch.randn(B, 8, 27, 27, device=dev, generator=gen) * 1.2     # clamp(-3,3) applies inside the step
-    text = torch.randn(B, 32, 256, device=dev, generator=gen)
-
-    if sample_mode:
-        graph = not args.no_graph
-        run = stepper.sampler(text, B, fast_sampling=False, use_graph=graph,
-                              noise_fn=lambda i, shape: torch.randn(shape, device=dev, generator=gen))
-        if graph and warmup < 2:
-            warmup = 2                                       # step 0 is eager, step 1 captures
-
-        def one_step():
-            run.step()
-            return None
-    elif fwd_bwd_only:
-        def one_step():
-            t = torch.randint(0, 1000, (B,), device=dev, generator=gen)
-            noise = torch.randn(B, 8, 27, 27, device=dev, generator=gen)
-            unet.train()
-            stepper.flag.zero_()
-            noisy = stepper.noise_scheduler.add_noise(latents, noise, t, clamp=True, flag=stepper.flag)
-            stepper.arena.zero()
-            eps = unet(noisy, t, text)
-            loss, dpred = stepper.smooth_l1(eps, noise)
-            eps.backward(dpred)
-            stepper.arena.finalize()
-            return {"loss": loss, "nan_flag": stepper.flag}
-    else:
-        def one_step():
-            t = torch.randint(0, 1000, (B,), device=dev, generator=gen)
-            noise = torch.randn(B, 8, 27, 27, device=dev, generator=gen)
-            return stepper.train_step(latents, text, t, noise)
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    out = None
-    for _ in range(warmup):
-        out = one_step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        out = one_step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if sample_mode:
-        loss, flag = None, int(not bool(torch.isfinite(run.x).all().item()))
-    else:
-        loss, flag = float(out["loss"].item()), int(out["nan_flag"].item())
-    # Roofline leg (rank 0, after the timed region): per-launch HIP-event times are only meaningful when a kernel has
-    # the GPU to itself, and the timed region above overlaps the weight-gradient GEMMs (second stream) with the
-    # data-gradient chain - so the same step runs `profile_steps` more times with that overlap switched off (and, in
-    # sample mode, eagerly: event records inside a replayed graph would not bracket the replayed kernels).
-    prof = None
-    if not args.no_profile:                   # every rank runs the extra steps (they contain the collective)
+    def make_steps(kind, batch, graph=True):
+        """(one_step, profile_step, state) of a workload; `kind` in train / fwd_bwd / sample.  The U-Net must already be
+        in the workload's compute dtype."""
+        latents = torch.randn(batch, 8, 27, 27, device=dev, generator=gen) * 1.2     # clamp(-3,3) applies inside the step
+        text = torch.randn(batch, 32, 256, device=dev, generator=gen)
+        if kind == "sample":
+            noise_fn = lambda i, shape: torch.randn(shape, device=dev, generator=gen)
+            run = stepper.sampler(text, batch, fast_sampling=False, use_graph=graph, noise_fn=noise_fn)
+
+            def prof_factory():
+                return stepper.sampler(text, batch, fast_sampling=False, use_graph=False, noise_fn=noise_fn).step
+            def sample_step():
+                run.step()
+                return None
+            return sample_step, prof_factory, run
+        if kind == "fwd_bwd":
+            def one_step():
+                t = torch.randint(0, 1000, (batch,), device=dev, generator=gen)
+                noise = torch.randn(batch, 8, 27, 27, device=dev, generator=gen)
+                unet.train()
+                stepper.flag.zero_()
+                noisy = stepper.noise_scheduler.add_noise(latents, noise, t, clamp=True, flag=stepper.flag)
+                stepper.arena.zero()
+                eps = unet(noisy, t, text)
+                loss, dpred = stepper.smooth_l1(eps, noise)
+                eps.backward(dpred)
+                stepper.arena.finalize()
+                if stepper.reducer is not None:
+                    stepper.reducer.finish()
+                return {"loss": loss, "nan_flag": stepper.flag}
+            return one_step, (lambda: one_step), None
+
+        def one_step():
+            t = torch.randint(0, 1000, (batch,), device=dev, generator=gen)
+            noise = torch.randn(batch, 8, 27, 27, device=dev, generator=gen)
+            return stepper.train_step(latents, text, t, noise)
+        return one_step, (lambda: one_step), None
+
+    def timed(one_step, nsteps, nwarm):
+        out = None
+        for _ in range(nwarm):
+            out = one_step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(nsteps):
+            out = one_step()
+        barrier()
+        el = time.perf_counter() - t0
+        tmax = torch.tensor([el], device=dev, dtype=torch.float64)
+        if world > 1:
+            torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+        return float(tmax.item()), out
+
+    def families(prof_factory, nsteps, peak):
+        """Roofline leg (after a timed region): per-launch HIP-event times are only meaningful when a kernel has the GPU to
+        itself, and the timed region overlaps the weight-gradient GEMMs (second stream) with the data-gradient chain - so
+        the same step runs `nsteps` more times with that overlap switched off (and, in sample mode, eagerly: event records
+        inside a replayed graph would not bracket the replayed kernels).  Every rank runs them (they hold the collective)."""
         overlap, ops.SideStream.enabled = ops.SideStream.enabled, False
-        if sample_mode:
-            prun = stepper.sampler(text, B, fast_sampling=False, use_graph=False,
-                                   noise_fn=lambda i, shape: torch.randn(shape, device=dev, generator=gen))
-            pstep = prun.step
-        else:
-            pstep = one_step
+        pstep = prof_factory()
         pstep()
         barrier()
         if rank == 0:
             _lib.check(lib.psg_profile_begin(), "psg_profile_begin")
-        for _ in range(args.profile_steps):
+        for _ in range(nsteps):
             pstep()
         barrier()
+        fam = None
         if rank == 0:
             n = len(KINDS)
             ms, work, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_int64 * n)()
             _lib.check(lib.psg_profile_end(ms, work, cnt, n), "psg_profile_end")
-            prof = [(KINDS[i], ms[i], work[i], cnt[i]) for i in range(n)]
+            fam = []
+            for i, name in enumerate(KINDS):
+                if cnt[i] == 0:
+                    continue
+                is_bytes = name == "groupnorm"
+                ach = work[i] / (ms[i] * 1e-3)
+                fam.append({"kernel": name, "launches_per_step": cnt[i] / nsteps, "ms_per_step": ms[i] / nsteps,
+                            "avg_launch_us": 1e3 * ms[i] / cnt[i], "bound": "hbm" if is_bytes else "mfma",
+                            "achieved": ach / (1e9 if is_bytes else 1e12), "unit": "GB/s" if is_bytes else "TFLOP/s",
+                            "peak": 8000.0 if is_bytes else peak / 1e12, "frac": ach / (8e12 if is_bytes else peak)})
         ops.SideStream.enabled = overlap
-    tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-    elapsed = float(tmax.item())
+        return fam
+
+    def roofline_of(fam, build_id, workload_key, nsteps):
+        dom = max(fam, key=lambda f: f["ms_per_step"])
+        # memory-side bytes per launch come from a SEPARATE rocprofv3 --pmc pass of this same command (PMC cannot be
+        # read from inside the process): attached only when a committed summary matches this build AND workload
+        traffic, traffic_src = _traffic_for(build_id, dom["kernel"], workload_key)
+        return {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
+                "frac": dom["frac"], "traffic": traffic, "traffic_unit": "bytes/launch (memory-side requests incl. Infinity-Cache hits)",
+                "traffic_source": traffic_src, "kernel": dom["kernel"],
+                "avg_launch_us": dom["avg_launch_us"], "launches_per_step": dom["launches_per_step"],
+                "ms_per_step": dom["ms_per_step"],
+                "how": "algorithmic 2*M*N*K FLOPs summed over the family's launches / HIP-event time on the launch stream, "
+                       f"{nsteps} steps run after the timed region with the wgrad side stream off (exclusive kernels)"}
+
+    kind = "sample" if sample_mode else ("fwd_bwd" if fwd_bwd_only else "train")
+    graph = not args.no_graph
+    if sample_mode and graph and warmup < 2:
+        warmup = 2                                       # step 0 is eager, step 1 captures
+    one_step, prof_factory, run = make_steps(kind, B, graph)
+    elapsed, out = timed(one_step, steps, warmup)
+    if sample_mode:
+        loss, flag = None, int(not bool(torch.isfinite(run.x).all().item()))
+    else:
+        loss, flag = float(out["loss"].item()), int(out["nan_flag"].item())
+    peak = PEAK_BF16 if dtype_name == "bf16" else PEAK_F32
+    fam = families(prof_factory, args.profile_steps, peak) if not args.no_profile else None
+
+    # ---- the other single-GPU BASELINE configs, same process, after the headline's timed region (N = 1 default run only) ----
+    secondary = None
+    if world == 1 and kind == "train" and dtype_name == "bf16" and not args.no_secondary and not args.rehearse and args.batch is None:
+        secondary = {}
+        build_id = _build_id()
+        # configs[1]: forward + SmoothL1 + backward, exact-fp32 MFMA, batch 64
+        unet.set_compute_dtype(torch.float32)
+        s1, p1, _ = make_steps("fwd_bwd", 64)
+        el1, o1 = timed(s1, 5, 2)
+        f1 = families(p1, 1, PEAK_F32) if not args.no_profile else None
+        sps1 = 5 * 64 / el1
+        secondary["fwd_bwd_fp32_bs64"] = {
+            "metric": "unet_fwd_bwd_steps_per_sec_bs64", "value": 5 / el1, "unit": "bs64-steps/s", "steps": 5, "warmup": 2,
+            "ms_per_step": 1e3 * el1 / 5, "dtype": "fp32", "samples_per_s": sps1,
+            "step_mfma_frac_of_peak": sps1 * FWD_BWD_GFLOP_PER_SAMPLE * 1e9 / PEAK_F32, "final_loss": float(o1["loss"].item()),
+            "config": {"workload": "BASELINE configs[1]: add_noise + U-Net forward + SmoothL1 + backward (no optimizer), batch 64, "
+                                   "fp32 (exact fp32 MFMA), train mode (dropout 0.05)"}}
+        if f1:
+            secondary["fwd_bwd_fp32_bs64"]["roofline"] = roofline_of(f1, build_id, "fwd_bwd_fp32_bs64", 1)
+        unet.set_compute_dtype(torch.bfloat16)
+        # configs[4] per GPU: denoising steps of the 1000-step DDPM loop, 64 samples, hipGraph replay
+        s4, p4, run4 = make_steps("sample", 64, True)
+        el4, _ = timed(s4, 30, 3)
+        f4 = families(p4, 3, PEAK_BF16) if not args.no_profile else None
+        secondary["sample_bf16_n64"] = {
+            "metric": "ddpm_denoise_steps_per_sec_n64", "value": 30 / el4, "unit": "denoise-steps/s (64 samples per GPU each)",
+            "steps": 30, "warmup": 3, "ms_per_step": 1e3 * el4 / 30, "dtype": "bf16", "samples_per_s": 30 * 64 / el4,
+            "step_mfma_frac_of_peak": (30 * 64 / el4) * FWD_GFLOP_PER_SAMPLE * 1e9 / PEAK_BF16,
+            "finite": bool(torch.isfinite(run4.x).all().item()),
+            "config": {"workload": "BASELINE configs[4] per GPU: DDPM sampling loop (ddpm_sample :508-569), 1000-step schedule, 64 samples, "
+                                   "U-Net forward + update per step, hipGraph replay, bf16 MFMA; 30 of the 1000 steps timed"}}
+        if f4:
+            secondary["sample_bf16_n64"]["roofline"] = roofline_of(f4, build_id, "sample_bf16_n64", 3)
+        unet.train()
 
     if rank == 0:
         steps_per_s = world * steps / elapsed
-        peak = PEAK_BF16 if dtype_name == "bf16" else PEAK_F32
         build_id = _build_id()
         if sample_mode:
             metric, unit = "ddpm_denoise_steps_per_sec_n64", "denoise-steps/s (64 samples per GPU each)"
@@ -374,32 +491,20 @@ def run_worker(args):
             "samples_per_s": samples_per_s,
             "step_mfma_frac_of_peak": samples_per_s * gflop * 1e9 / (peak * world),
             "final_loss": loss, "nan_flag": flag, "build_id": build_id,
-            "nccl_world_size": nccl_world,
-            "allreduce_bytes_per_step": (stepper.reducer.bytes_per_step if stepper.reducer is not None and not sample_mode and not fwd_bwd_only else 0),
+            "nccl_world_size": nccl_world, "collective_backend": backend,
+            "allreduce_bytes_per_step": (stepper.reducer.bytes_per_step if stepper.reducer is not None and not sample_mode else 0),
         }
-        if prof:
-            fam = []
-            for name, ms_k, work_k, cnt_k in prof:
-                if cnt_k == 0:
-                    continue
-                is_bytes = name == "groupnorm"
-                ach = work_k / (ms_k * 1e-3)
-                fam.append({"kernel": name, "launches_per_step": cnt_k / args.profile_steps, "ms_per_step": ms_k / args.profile_steps,
-                            "avg_launch_us": 1e3 * ms_k / cnt_k, "bound": "hbm" if is_bytes else "mfma",
-                            "achieved": ach / (1e9 if is_bytes else 1e12), "unit": "GB/s" if is_bytes else "TFLOP/s",
-                            "peak": 8000.0 if is_bytes else peak / 1e12, "frac": ach / (8e12 if is_bytes else peak)})
-            dom = max(fam, key=lambda f: f["ms_per_step"])
-            # memory-side bytes per launch come from a SEPARATE rocprofv3 --pmc pass of this same command (PMC cannot be
-            # read from inside the process): attached only when a committed summary matches this build AND workload
-            traffic, traffic_src = _traffic_for(build_id, dom["kernel"], workload_key)
-            res["roofline"] = {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
-                               "frac": dom["frac"], "traffic": traffic, "traffic_unit": "bytes/launch (memory-side requests incl. Infinity-Cache hits)",
-                               "traffic_source": traffic_src, "kernel": dom["kernel"],
-                               "avg_launch_us": dom["avg_launch_us"], "launches_per_step": dom["launches_per_step"],
-                               "ms_per_step": dom["ms_per_step"],
-                               "how": "algorithmic 2*M*N*K FLOPs summed over the family's launches / HIP-event time on the launch stream, "
-                                      f"{args.profile_steps} steps run after the timed region with the wgrad side stream off (exclusive kernels)"}
+        if stepper.reducer is not None and not sample_mode:
+            res["allreduce_buckets"] = len(stepper.reducer.buckets)
+            res["allreduce_buckets_launched_during_backward"] = stepper.reducer.launched_early
+            res["allreduce_avg_in_collective"] = stepper.reducer.avg_in_collective
+        if args.rehearse:
+            res["rehearsal"] = "N workers on ONE GPU over gloo: plumbing check, not a throughput figure"
+        if fam:
+            res["roofline"] = roofline_of(fam, build_id, workload_key, args.profile_steps)
             res["kernel_families"] = fam
+        if secondary:
+            res["secondary"] = secondary
         if not args.no_cpu_baseline and world == 1:
             try:
                 res["cpu_baseline"] = cpu_baseline()

@@ -165,6 +165,14 @@ def ptr(t):
 # grow-only device workspace (one per device; all kernels run on the current stream in order)
 # ---------------------------------------------------------------------------
 _ws = {}
+_ws_frozen = False
+
+
+def freeze_workspaces(on: bool):
+    """While frozen (a hipGraph capture is open) a request that would REPLACE a workspace raises: kernels already captured
+    keep pointing at the old buffer, so growth must have happened in the eager warm-up on the same stream."""
+    global _ws_frozen
+    _ws_frozen = bool(on)
 
 
 def workspace(nbytes: int, device):
@@ -174,6 +182,9 @@ def workspace(nbytes: int, device):
     key = (di, _raw_stream(di) if _raw_stream is not None else torch.cuda.current_stream(device).cuda_stream)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
+        if _ws_frozen:
+            raise PsgError(f"workspace of {nbytes} bytes requested inside a graph capture but the warm-up sized "
+                           f"{0 if buf is None else buf.numel()} on this stream: run the eager warm-up on the capture stream")
         buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _ws[key] = buf
     return buf

@@ -24,15 +24,63 @@ def dist_info():
     return 0, 1
 
 
+def rank_generator(device, rank=None, world=None):
+    """Generator for the per-sample random draws of a data-parallel rank (timesteps, noise, the VAE's reparameterisation
+    eps), or None (= torch's default generator) in a single process.  The reference's loaders seed every process alike
+    (dataset_improved.py:254), which the loader shuffle NEEDS (ddp.ShardedLoader) - but the same seed on every device
+    generator would hand all N shards of a global batch identical t / noise / eps: B/N distinct draws instead of B.
+    Seed: torch.initial_seed() + rank (the CPU generator stays shared, so shuffles still agree)."""
+    if rank is None or world is None:
+        rank, world = dist_info()
+    if world <= 1:
+        return None
+    g = torch.Generator(device=device)
+    g.manual_seed((torch.initial_seed() + 0x9E3779B97F4A7C15 * (int(rank) + 1)) & 0x7FFFFFFFFFFFFFFF)
+    return g
+
+
+def _digest(batch):
+    """Order-sensitive 64-bit digest of a batch's tensors and strings (ShardedLoader's agreement check)."""
+    import zlib
+    acc = 0
+    vals = batch.values() if isinstance(batch, dict) else (batch if isinstance(batch, (list, tuple)) else [batch])
+    for v in vals:
+        if torch.is_tensor(v):
+            b = v.detach().cpu().contiguous().view(torch.uint8).numpy().tobytes() if v.numel() else b""
+        elif isinstance(v, (list, tuple)):
+            b = "\x1f".join(str(e) for e in v).encode()
+        else:
+            b = str(v).encode()
+        acc = (acc * 1000003 + zlib.crc32(b)) & 0x7FFFFFFFFFFFFFFF
+    return acc
+
+
 class ShardedLoader:
     """Rank r's view of a loader that yields GLOBAL batches: the contiguous slice [r*n/N, (r+1)*n/N) of every batch
     (SURVEY.md §8e), for loaders that were built without a DistributedSampler (the reference's `create_data_loaders`).
     All ranks must iterate the same batches in the same order (same seed / shuffle state on every rank); a ragged last
     batch is trimmed to a multiple of the world size so every rank steps the same number of times with equal weight.
-    Works on dict batches (tensors, lists, tuples sliced along dim 0), tensors and tuples/lists of tensors."""
+    Works on dict batches (tensors, lists, tuples sliced along dim 0), tensors and tuples/lists of tensors.
 
-    def __init__(self, loader, rank, world):
+    `verify` (default: whenever a process group exists): the FIRST global batch of every epoch is digested on each rank
+    and the digests are compared through one tiny all-reduce (MIN and MAX of the digest); ranks that shuffled differently
+    would otherwise train silently on overlapping / incoherent shards - here they raise on every rank at once."""
+
+    def __init__(self, loader, rank, world, verify=None, group=None):
         self.loader, self.rank, self.world = loader, int(rank), int(world)
+        self.verify = (dist.is_available() and dist.is_initialized() and self.world > 1) if verify is None else bool(verify)
+        self.group = group
+
+    def _check_agreement(self, batch):
+        d = _digest(batch)
+        dev = "cuda" if dist.get_backend(self.group) == "nccl" else "cpu"
+        lo = torch.tensor([d], dtype=torch.int64, device=dev)
+        hi = lo.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=self.group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=self.group)
+        if int(lo.item()) != int(hi.item()):
+            raise RuntimeError("ShardedLoader: ranks iterate DIFFERENT global batches (first-batch digests disagree): the loaders "
+                               "must be seeded alike on every rank (same shuffle state) - see INTEGRATION.md")
 
     def __len__(self):
         return len(self.loader)
@@ -56,7 +104,11 @@ class ShardedLoader:
         raise TypeError("ShardedLoader: cannot find the batch dimension")
 
     def __iter__(self):
+        first = True
         for batch in self.loader:
+            if first and self.verify:
+                self._check_agreement(batch)
+            first = False
             n = self._batch_size(batch)
             per = n // self.world
             if per == 0:                     # fewer samples than ranks: every rank skips it together
@@ -81,14 +133,7 @@ class BucketedAllReduce:
             raise ValueError("BucketedAllReduce: bucket_dtype must be float32 or bfloat16")
         self.bucket_dtype = bucket_dtype
         # RCCL averages inside the collective (ncclAvg): no extra pass over the 2.56 GB arena; gloo sums, then scales
-        self.avg_in_collective = False
-        if dist.is_initialized() and self.world > 1 and dist.get_backend(process_group) == "nccl":
-            try:                                   # every rank runs the same probe, so a refusal is collective too
-                probe = torch.ones(1, dtype=torch.float32, device=self.flat.device)
-                dist.all_reduce(probe, op=dist.ReduceOp.AVG, group=process_group)
-                self.avg_in_collective = abs(float(probe.item()) - 1.0) < 1e-6
-            except Exception:                      # noqa: BLE001 - older RCCL without ncclAvg: sum, then scale
-                self.avg_in_collective = False
+        self.avg_in_collective = self._avg_capability(process_group)
         self.op = dist.ReduceOp.AVG if self.avg_in_collective else dist.ReduceOp.SUM
         self.buckets = []          # (start, end, [param indices])
         cap = max(1, bucket_bytes // 4)
@@ -112,12 +157,34 @@ class BucketedAllReduce:
         if bucket_dtype != torch.float32:
             self._staging = torch.empty(self.flat.numel(), dtype=bucket_dtype, device=self.flat.device)
         self.bytes_per_step = self.flat.numel() * (2 if bucket_dtype == torch.bfloat16 else 4)
+        self.launched_early = 0            # buckets of the LAST finished step that left before finish() (overlap evidence)
+        self._early = 0
         self.reset()
 
+    def _avg_capability(self, group):
+        """ncclAvg or sum-then-scale - decided WITHOUT a trial collective (an exception on one rank only would leave the
+        others inside it): the local answer comes from the library version (ncclAvg exists since NCCL 2.10; RCCL reports
+        its NCCL API level), and the ranks then agree on the MINIMUM of their answers through a plain SUM-free MIN
+        all-reduce that every backend supports, so a mixed installation falls back together."""
+        if not (dist.is_available() and dist.is_initialized()) or self.world <= 1 or dist.get_backend(group) != "nccl":
+            return False
+        try:
+            ver = torch.cuda.nccl.version()
+            ver = tuple(ver) if isinstance(ver, (tuple, list)) else (ver // 1000, (ver // 100) % 10, ver % 100)
+            local = 1 if tuple(ver[:2]) >= (2, 10) else 0
+        except Exception:                          # noqa: BLE001 - no version query: assume the old API
+            local = 0
+        agree = torch.tensor([local], dtype=torch.int32, device=self.flat.device)
+        dist.all_reduce(agree, op=dist.ReduceOp.MIN, group=group)
+        return bool(int(agree.item()))
+
     def reset(self):
+        """Back to 'no gradient seen' (start of a step; also the recovery point after a failed step: pending counters and
+        outstanding work handles of a half-finished exchange are dropped)."""
         for b, (_, _, mem) in enumerate(self.buckets):
             self._pending[b] = len(mem)
         self._works = []
+        self._early = 0
 
     def on_ready(self, i):
         """Called (by the gradient sink) when parameter i's gradient is final for this step."""
@@ -126,6 +193,7 @@ class BucketedAllReduce:
         b = self._bucket_of[i]
         self._pending[b] -= 1
         if self._pending[b] == 0:
+            self._early += 1
             self._launch(b)
 
     def _reduce(self, s, e):
@@ -172,4 +240,6 @@ class BucketedAllReduce:
             torch.cuda.current_stream().wait_stream(self._stream)
         if not self.avg_in_collective:
             self.flat.mul_(1.0 / self.world)
+        early = self._early
         self.reset()
+        self.launched_early = early

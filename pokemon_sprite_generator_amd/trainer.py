@@ -31,8 +31,8 @@ import torch
 
 from . import _lib
 from . import ops as ops_mod
-from ._lib import FLAG_INPUT_BAD, FLAG_LOSS_BAD, FLAG_PRED_BAD, FLAG_SKIP_MASK, check, ptr, stream_ptr
-from .ddp import BucketedAllReduce, ShardedLoader, dist_info
+from ._lib import FLAG_INPUT_BAD, FLAG_LOSS_BAD, FLAG_NOISY_BAD, FLAG_PRED_BAD, FLAG_SKIP_MASK, FLAG_T_RANGE, check, ptr, stream_ptr
+from .ddp import BucketedAllReduce, ShardedLoader, dist_info, rank_generator
 from .optim import FusedAdamW, GradArena, ParamArena
 from .scheduler import NoiseScheduler
 from .unet import UNet
@@ -88,11 +88,30 @@ class DiffusionStepper:
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.criterion_beta = 0.1                                               # nn.SmoothL1Loss(beta=0.1) :300
         self.host_steps = 0                                                     # (torch.optim.Adam branch only)
+        # data parallel: this rank's own stream for t / noise / VAE eps (None = torch's default generator); see ddp.rank_generator
+        self.generator = rank_generator(self.device) if distributed else None
+        self._seed_source_owner = False
 
     def close(self):
-        """Release the process-wide registrations (gradient sinks, bf16 shadow) of this stepper."""
+        """Release the process-wide registrations (gradient sinks, bf16 shadow, the graph-replay seed word) of this stepper."""
         self.arena.release()
         self.params.release()
+        if self._seed_source_owner:                # (capture_train_step switched the dropout seeds to the device word)
+            ops_mod.SeedSource.disable()
+            self._seed_source_owner = False
+
+    def randn_like(self, x):
+        """randn_like from this rank's stream (:373)."""
+        if self.generator is None:
+            return torch.randn_like(x)
+        return torch.randn(x.shape, dtype=x.dtype, device=x.device, generator=self.generator)
+
+    def randint_t(self, n):
+        """Timesteps of a batch (:366) from this rank's stream."""
+        T = self.noise_scheduler.num_timesteps
+        if self.generator is None:
+            return torch.randint(0, T, (n,), device=self.device)
+        return torch.randint(0, T, (n,), device=self.device, generator=self.generator)
 
     # ---- fused SmoothL1 + dL/d(eps_hat) ------------------------------------------------------------
     def smooth_l1(self, pred, target, want_grad=True):
@@ -124,7 +143,7 @@ class DiffusionStepper:
             from .unet import _SeedStream
             _SeedStream.counter = 0
         if noise is None:
-            noise = torch.randn_like(latents)
+            noise = self.randn_like(latents)
         self.flag.zero_()
         if pre_flag is not None:
             self.flag |= pre_flag.to(device=self.device, dtype=torch.int32).reshape(-1)[:1]
@@ -159,7 +178,10 @@ class DiffusionStepper:
         reads (flags, step count and schedule live on the device) and its dropout masks keep changing between replays
         through `ops.SeedSource`; noise is drawn inside the graph (torch's graph-safe generator).  `warmup` eager steps run
         first ON THE GIVEN BATCH (they train); capture itself executes nothing.  Single process only (no gradient
-        all-reduce inside the graph).  23 ms of launches per step become one replay: the step is GPU-bound at any batch."""
+        all-reduce inside the graph).  23 ms of launches per step become one replay: the step is GPU-bound at any batch.
+        MODE SWITCH: capturing enables `ops.SeedSource` (fixed per-site dropout seeds + a device word advanced every step)
+        for the whole process - eager steps of this and any other stepper draw their masks that way too from then on -
+        until this stepper's `close()` (or `ops.SeedSource.disable()`) switches it back."""
         if self.reducer is not None:
             raise NotImplementedError("capture_train_step: data-parallel steps are not captured")
         if not isinstance(self.optimizer, FusedAdamW):
@@ -175,7 +197,7 @@ class DiffusionStepper:
         """validate_epoch body (:465-486)."""
         self.unet.eval()
         if noise is None:
-            noise = torch.randn_like(latents)
+            noise = self.randn_like(latents)
         self.flag.zero_()
         noisy = self.noise_scheduler.add_noise(latents, noise, t, clamp=True, flag=self.flag)
         eps_hat = self.unet(noisy, t, text_emb)
@@ -216,18 +238,26 @@ class GraphedTrainStep:
         from .ops import SeedSource, WeightCache
         self.stepper = stepper
         dev = stepper.device
+        if not SeedSource.enabled():
+            stepper._seed_source_owner = True
         SeedSource.enable(dev)
         self.lat, self.txt, self.t = latents.detach().clone(), text_emb.detach().clone(), t.detach().clone()
+        # Warm-up AND capture run on ONE stream of ours: the scratch workspace is keyed by (device, stream), so the eager
+        # steps size exactly the buffers the captured launches will use and nothing is (re)allocated inside the capture.
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(side):
             for _ in range(max(1, warmup)):
                 stepper.train_step(self.lat, self.txt, self.t)
+            torch.cuda.synchronize(dev)
+            self.graph = torch.cuda.CUDAGraph()
+            _lib.freeze_workspaces(True)           # a growing request inside the capture raises instead of replacing a captured buffer
+            try:
+                with torch.cuda.graph(self.graph, stream=side):
+                    self.out = stepper.train_step(self.lat, self.txt, self.t)
+            finally:
+                _lib.freeze_workspaces(False)
         torch.cuda.current_stream(dev).wait_stream(side)
-        torch.cuda.synchronize(dev)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = stepper.train_step(self.lat, self.txt, self.t)
         WeightCache.invalidate()
 
     def run(self, latents=None, text_emb=None, t=None):
@@ -279,6 +309,10 @@ class SamplerRun:
         self.use_graph = bool(use_graph) and len(self.order) > 2
         self.graph = None
         self.i = 0
+        # graph mode: eager step 0, the capture and every replay run on ONE stream of ours - the scratch workspace is keyed
+        # by (device, stream), so step 0 sizes exactly the buffers the captured launches use (nothing is allocated or
+        # replaced inside the capture: _lib.freeze_workspaces enforces it)
+        self._stream = torch.cuda.Stream(device=dev) if self.use_graph else None
 
     def remaining(self):
         return len(self.order) - self.i
@@ -295,13 +329,29 @@ class SamplerRun:
             raise StopIteration("sampler chain is complete")
         self.st.unet.eval()
         DiffusionStepper._sample_set(self.order[self.i], self.i, self.tv, self.t_dev, self.z, self.rnd, self.x)
+        if self._stream is None:
+            self._body()
+        else:
+            cur = torch.cuda.current_stream(self.st.device)
+            self._stream.wait_stream(cur)
+            with torch.cuda.stream(self._stream):
+                self._graph_step()
+            cur.wait_stream(self._stream)
+        self.i += 1
+        return self.x
+
+    def _graph_step(self):
         if self.use_graph and self.i == 1 and self.graph is None:
             try:
                 torch.cuda.synchronize(self.st.device)
                 graph = torch.cuda.CUDAGraph()
                 x_before = self.x.clone()
-                with torch.cuda.graph(graph):
-                    self._body()
+                _lib.freeze_workspaces(True)
+                try:
+                    with torch.cuda.graph(graph, stream=self._stream):
+                        self._body()
+                finally:
+                    _lib.freeze_workspaces(False)
                 self.x.copy_(x_before)                  # capture does not execute: the replay below runs this step
                 self.graph = graph
             except Exception as e:                      # noqa: BLE001
@@ -311,8 +361,6 @@ class SamplerRun:
             self.graph.replay()
         else:
             self._body()
-        self.i += 1
-        return self.x
 
 
 def schedule_tables(make_scheduler, lr, betas, total):
@@ -347,6 +395,10 @@ class ImprovedDiffusionTrainer:
             compute_dtype = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32,
                              "float32": torch.float32}[str(mi.get("dtype", "bf16"))]
         self.compute_dtype = compute_dtype
+        # the frozen VAE either side of the path runs in fp32 like the reference's (the latents the U-Net trains on and the
+        # monitoring images then carry fp32-grade error, 1e-3, not bf16's 3e-2); `mi355x.vae_dtype: bf16` trades that for speed
+        self.vae_dtype = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32,
+                          "float32": torch.float32}[str(mi.get("vae_dtype", "fp32"))]
         self._grad_bucket_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[str(mi.get("grad_bucket_dtype", "fp32"))]
         if not torch.cuda.is_available():
             raise _lib.PsgError("ImprovedDiffusionTrainer (MI355X build) needs a GPU; there is no CPU fallback")
@@ -391,7 +443,7 @@ class ImprovedDiffusionTrainer:
         if name in ("VAEEncoder", "VAEDecoder"):          # the frozen VAE either side of the path runs on the kernels too
             from . import vae
             cls = getattr(vae, name)
-            return lambda *a, **k: cls(*a, compute_dtype=self.compute_dtype, **k)
+            return lambda *a, **k: cls(*a, compute_dtype=self.vae_dtype, **k)
         try:                                   # the reference package, when this class is dropped into its tree
             import importlib
             mod = importlib.import_module({"create_data_loaders": "src.data"}.get(name, "src.models"))
@@ -403,24 +455,40 @@ class ImprovedDiffusionTrainer:
     def setup_models(self):
         mc = self.config["model"]
         latent_dim = mc.get("latent_dim", 8)
-        if "text_encoder" in self._components:
-            self.text_encoder = self._components["text_encoder"]
-            self.vae_encoder = self._components["vae_encoder"]
-            self.vae_decoder = self._components.get("vae_decoder")
+        # Each collaborator is taken from `components=` when injected (an INSTANCE: `text_encoder`, `vae_encoder`,
+        # `vae_decoder`), else built the reference's way (:150-225): BERT text encoder from the reference package, the frozen
+        # VAE from THIS package's kernels, both loaded from the stage-1 checkpoint.  Any subset may be injected.
+        comps = self._components
+        ckpt = {}
+        if not all(k in comps for k in ("text_encoder", "vae_encoder", "vae_decoder")):
+            if os.path.exists(str(self.vae_checkpoint_path)):
+                print(f"Loading VAE from {self.vae_checkpoint_path}")
+                ckpt = torch.load(self.vae_checkpoint_path, map_location=self.device)
+            elif "vae_encoder" not in comps:
+                raise FileNotFoundError(f"VAE checkpoint {self.vae_checkpoint_path} not found (needed for the frozen VAE encoder)")
+        if "text_encoder" in comps:
+            self.text_encoder = comps["text_encoder"]
         else:
-            TextEncoder, VAEEncoder, VAEDecoder = (self._component(n) for n in ("TextEncoder", "VAEEncoder", "VAEDecoder"))
+            TextEncoder = self._component("TextEncoder")
             self.text_encoder = TextEncoder(model_name=mc["bert_model"], hidden_dim=mc["text_embedding_dim"]).to(self.device)
-            print(f"Loading VAE from {self.vae_checkpoint_path}")
-            ckpt = torch.load(self.vae_checkpoint_path, map_location=self.device)
-            self.vae_encoder = VAEEncoder(input_channels=3, latent_dim=latent_dim).to(self.device)
-            self.vae_decoder = VAEDecoder(latent_dim=latent_dim, text_dim=mc["text_embedding_dim"], output_channels=3).to(self.device)
-            if "vae_state_dict" in ckpt:
-                enc = {k[8:]: v for k, v in ckpt["vae_state_dict"].items() if k.startswith("encoder.")}
-                dec = {k[8:]: v for k, v in ckpt["vae_state_dict"].items() if k.startswith("decoder.")}
-                self.vae_encoder.load_state_dict(enc, strict=False)
-                self.vae_decoder.load_state_dict(dec, strict=False)
             if "text_encoder_state_dict" in ckpt:
                 self.text_encoder.load_state_dict(ckpt["text_encoder_state_dict"], strict=False)
+        vsd = ckpt.get("vae_state_dict") if isinstance(ckpt, dict) else None
+        if "vae_encoder" in comps:
+            self.vae_encoder = comps["vae_encoder"]
+        else:
+            self.vae_encoder = self._component("VAEEncoder")(input_channels=3, latent_dim=latent_dim).to(self.device)
+            if vsd is not None:
+                self.vae_encoder.load_state_dict({k[8:]: v for k, v in vsd.items() if k.startswith("encoder.")}, strict=False)
+        if "vae_decoder" in comps:
+            self.vae_decoder = comps["vae_decoder"]
+        elif "vae_encoder" in comps and vsd is None:
+            self.vae_decoder = None               # (stub encoder and no stage-1 checkpoint: monitoring images are skipped)
+        else:
+            self.vae_decoder = self._component("VAEDecoder")(latent_dim=latent_dim, text_dim=mc["text_embedding_dim"],
+                                                             output_channels=3).to(self.device)
+            if vsd is not None:
+                self.vae_decoder.load_state_dict({k[8:]: v for k, v in vsd.items() if k.startswith("decoder.")}, strict=False)
         for m in (self.text_encoder, self.vae_encoder, self.vae_decoder):
             if isinstance(m, torch.nn.Module):
                 for p in m.parameters():
@@ -535,7 +603,13 @@ class ImprovedDiffusionTrainer:
         images = batch["image"].to(self.device)
         with torch.no_grad():
             text_emb = self.text_encoder(batch["full_description"])
-            latent = self.vae_encoder(images)
+            gen = self.stepper.generator
+            from .vae import VAEEncoder as _OwnEncoder
+            if gen is not None and isinstance(self.vae_encoder, _OwnEncoder):      # this rank's own reparameterisation noise
+                eps = torch.randn((images.shape[0], self.vae_encoder.latent_dim, 27, 27), device=self.device, generator=gen)
+                latent = self.vae_encoder(images, eps)
+            else:
+                latent = self.vae_encoder(images)
             latent = latent[0] if isinstance(latent, (tuple, list)) else latent
             latent, text_emb = latent.float(), text_emb.float()
             bad = ~(torch.isfinite(text_emb).all() & torch.isfinite(latent).all())
@@ -549,13 +623,16 @@ class ImprovedDiffusionTrainer:
         for batch_idx, batch in enumerate(self.data_loaders["train"]):
             try:
                 latent, text_emb, pre = self._encode(batch)
-                t = torch.randint(0, self.noise_scheduler.num_timesteps, (latent.shape[0],), device=dev)
+                t = self.stepper.randint_t(latent.shape[0])
                 out = self.train_step(latent, text_emb, t, pre_flag=pre)
                 flag = out["nan_flag"]
                 good = (flag & FLAG_SKIP_MASK) == 0
                 total += torch.where(good, out["loss"], torch.zeros_like(out["loss"]))
                 counts[0] += good.reshape(()).to(torch.int64)
-                counts[1] += ((flag & (FLAG_PRED_BAD | FLAG_LOSS_BAD)) != 0).reshape(()).to(torch.int64)
+                # the reference counts a NaN batch only at :384 / :392 (prediction, loss); a bad INPUT or noisy latent
+                # `continue`s earlier (:353-376) and is not counted - a NaN input also poisons the prediction, so mask it
+                early = (flag & (FLAG_INPUT_BAD | FLAG_NOISY_BAD | FLAG_T_RANGE)) != 0
+                counts[1] += (((flag & (FLAG_PRED_BAD | FLAG_LOSS_BAD)) != 0) & ~early).reshape(()).to(torch.int64)
                 if batch_idx % log_every == 0:                      # the only host syncs of the loop
                     if int(flag.item()) & FLAG_SKIP_MASK:
                         self.logger.warning(f"NaN/Inf detected (flag {int(flag.item())}), batch skipped")
@@ -567,6 +644,12 @@ class ImprovedDiffusionTrainer:
                     self.writer.add_scalar("Diffusion Train/Gradient_Norm", out["grad_norm"].item(), step)
             except Exception as e:                                 # noqa: BLE001  (reference :433-435 logs and continues)
                 self.logger.error(f"Error in training batch {batch_idx}: {e}")
+                if self.world > 1:
+                    # one rank skipping a batch leaves the others inside the bucket all-reduce and its own bucket counters
+                    # half consumed: drop the exchange state and fail the job instead of hanging / desynchronising it
+                    if self.stepper.reducer is not None:
+                        self.stepper.reducer.reset()
+                    raise
                 continue
         nb, nan_count = (int(v) for v in counts.tolist())
         if nb == 0:
@@ -583,7 +666,7 @@ class ImprovedDiffusionTrainer:
         for batch in self.data_loaders["val"]:
             try:
                 latent, text_emb, _ = self._encode(batch)          # (the reference does not check the inputs here)
-                t = torch.randint(0, self.noise_scheduler.num_timesteps, (latent.shape[0],), device=dev)
+                t = self.stepper.randint_t(latent.shape[0])
                 loss, flag = self.stepper.eval_loss(latent, text_emb, t)
                 good = (flag & (FLAG_PRED_BAD | FLAG_LOSS_BAD)) == 0                                  # :482-489
                 total += torch.where(good, loss, torch.zeros_like(loss))

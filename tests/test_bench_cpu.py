@@ -42,3 +42,15 @@ def test_bench_under_torchrun_env_is_a_worker():
     assert all(p.returncode == 0 for p in procs)
     js = [[l for l in o.splitlines() if l.startswith("{")] for o in outs]
     assert len(js[0]) == 1 and json.loads(js[0][0])["ranks_seen"] == 2 and js[1] == []      # only rank 0 prints the line
+
+
+def test_bench_relays_a_failed_rank():
+    """A rank > 0 that dies must be readable from the driver's tail: its output and exit code are relayed on stderr (it used to
+    go to DEVNULL), the surviving rank is stopped at the timeout, and the launcher exits non-zero."""
+    e = dict(os.environ, PSG_BENCH_FAIL_RANK="1", PSG_BENCH_TIMEOUT="25")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "PSG_BENCH_WORKER"):
+        e.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], capture_output=True, text=True,
+                       timeout=300, env=e)
+    assert r.returncode != 0
+    assert "rank 1 (exit 3)" in r.stderr and "injected failure" in r.stderr, r.stderr[-2000:]

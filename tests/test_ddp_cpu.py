@@ -142,3 +142,63 @@ def test_arena_displacement_is_loud():
     ga2.release()
     assert GradSink.get(ps[0]) is None and GradSink.get(other[0]) is not None
     gb.release()
+
+
+def _rng_worker(rank, world, port, q, same_shuffle):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from pokemon_sprite_generator_amd.ddp import ShardedLoader, rank_generator
+        torch.manual_seed(1234)                       # the reference seeds every process alike (dataset_improved.py:254)
+        gen = rank_generator(torch.device("cpu"))
+        t = torch.randint(0, 1000, (16,), generator=gen)
+        noise = torch.randn(4, 8, generator=gen)
+        shuffle = torch.randperm(12)                  # default generator: must still agree across ranks
+        # every rank iterates the same global batches and keeps its own slice; a rank that shuffled differently is caught
+        order = shuffle if same_shuffle or rank == 0 else torch.flip(shuffle, dims=[0])
+        data = torch.arange(12 * 3).reshape(12, 3)[order]
+        batches = [{"image": data[i:i + 4], "full_description": [f"s{int(v)}" for v in order[i:i + 4]]} for i in range(0, 12, 4)]
+        err, mine = None, None
+        try:
+            mine = [b["image"].clone() for b in ShardedLoader(batches, rank, world)]
+        except RuntimeError as e:
+            err = str(e)
+        q.put((rank, t, noise, shuffle, mine, err))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, None, None, None, None, "worker: " + repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("same_shuffle", [True, False])
+def test_ranks_draw_their_own_t_and_noise_but_share_the_shuffle(same_shuffle):
+    """with every process seeded alike, all ranks used to draw identical timesteps / noise for their
+    different shards.  `ddp.rank_generator` gives each rank its own stream for those draws while the default generator (the
+    loader shuffle) stays shared; `ShardedLoader` verifies that the ranks really iterate the same global batches."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rng_worker, args=(r, 2, port, q, same_shuffle)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+    (r0, t0, n0, s0, m0, e0), (r1, t1, n1, s1, m1, e1) = res
+    assert t0 is not None and t1 is not None, (e0, e1)
+    assert not torch.equal(t0, t1) and not torch.equal(n0, n1)          # per-rank draws differ ...
+    assert torch.equal(s0, s1)                                            # ... the shared CPU stream does not
+    if same_shuffle:
+        assert e0 is None and e1 is None
+        for a, b in zip(m0, m1):                                         # disjoint halves of the same global batch
+            assert a.shape == b.shape == (2, 3) and not torch.equal(a, b)
+    else:
+        assert e0 is not None and e1 is not None and "DIFFERENT global batches" in e0 and "DIFFERENT global batches" in e1
+
+
+def test_rank_generator_single_process_is_the_default_stream():
+    from pokemon_sprite_generator_amd.ddp import rank_generator
+    assert rank_generator(torch.device("cpu")) is None                   # world 1: torch's default generator (reference behaviour)
+    a, b = rank_generator(torch.device("cpu"), 0, 4), rank_generator(torch.device("cpu"), 3, 4)
+    assert a.initial_seed() != b.initial_seed()

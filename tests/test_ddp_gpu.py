@@ -143,3 +143,134 @@ def test_two_rank_step_matches_single_process(backend, bucket_dtype):
         assert torch.equal(res[0][3][k], res[1][3][k]), k
         if sd[k].dtype.is_floating_point:
             assert float((res[0][3][k] - sd[k].cpu()).abs().max()) < (1e-5 if bucket_dtype == "fp32" else 2.5e-3), k
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# configs[3] rehearsed at production size on ONE GPU: the full-width 640 M-parameter U-Net, bf16 compute, the production
+# bucket size (64 MiB minimum -> 27 buckets of the 2.56 GB gradient arena), 2 ranks x batch 2 over gloo on cuda:0.
+# ---------------------------------------------------------------------------------------------------------------------
+N_PARAMS = 640_488_456
+
+
+def _full_batch():
+    g = torch.Generator().manual_seed(11)
+    return (torch.randn(4, 8, 27, 27, generator=g) * 1.2, torch.randn(4, 32, 256, generator=g),
+            torch.tensor([10, 400, 700, 999]), torch.randn(4, 8, 27, 27, generator=g))
+
+
+def _full_step(distributed, sl, bucket_dtype):
+    import pokemon_sprite_generator_amd as psg
+    import pokemon_sprite_generator_amd.unet as U
+    U.ATTN_DROPOUT = 0.0                     # dropout seeds mix in the rank: off, so 2 x 2 samples == 1 x 4 samples
+    torch.manual_seed(0)
+    unet = psg.UNet(compute_dtype=torch.bfloat16).cuda()
+    if distributed and torch.distributed.get_rank() == 1:       # replicas are made equal by the broadcast, not the seed
+        with torch.no_grad():
+            unet.init_conv.weight.add_(0.25)
+    st = psg.DiffusionStepper(unet, psg.NoiseScheduler(), lr=1e-3, weight_decay=0.0, max_grad_norm=1e9, distributed=distributed,
+                              grad_bucket_dtype=torch.bfloat16 if bucket_dtype == "bf16" else torch.float32)
+    lat, txt, t, nz = _full_batch()
+    out = st.train_step(lat[sl].cuda(), txt[sl].cuda(), t[sl].cuda(), nz[sl].cuda())
+    torch.cuda.synchronize()
+    return st, out
+
+
+def _exact_digest(flat):
+    """Two exact integer digests of a float tensor's bit patterns (equal digests <=> equal bits, for all practical purposes)."""
+    bits = flat.view(torch.int32).to(torch.int64)
+    return int(bits.sum().item()), int((bits * ((torch.arange(bits.numel(), device=bits.device) % 8191) + 1)).sum().item())
+
+
+def _full_worker(rank, world, port, q, bucket_dtype, ref_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import numpy as np
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        st, out = _full_step(True, slice(2 * rank, 2 * rank + 2), bucket_dtype)
+        red = st.reducer
+        ref = torch.from_numpy(np.load(ref_path)).cuda()
+        got = st.arena.flat
+        err_max = float((got - ref).abs().max() / ref.abs().max())
+        # per bucket, so that a small-gradient bucket cannot hide behind a large one
+        worst_bucket = max(float((got[s:e] - ref[s:e]).norm() / (ref[s:e].norm() + 1e-30)) for s, e, _ in red.buckets)
+        q.put((rank, {"loss": float(out["loss"].item()), "flag": int(out["nan_flag"].item()), "err_max": err_max, "worst_bucket": worst_bucket,
+                      "grad_digest": _exact_digest(got), "param_digest": _exact_digest(st.params.flat),
+                      "buckets": len(red.buckets), "early": red.launched_early, "bytes": red.bytes_per_step, "world": red.world,
+                      "numel": int(st.arena.numel), "steps": st.steps_done()}))
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bucket_dtype", ["fp32", "bf16"])
+def test_full_width_two_rank_step(bucket_dtype, tmp_path):
+    """BASELINE configs[3] on the box we have: production arena, production buckets, bucket-ready callbacks from the real
+    backward, the all-reduce overlapping it, NaN-flag reduce, clip, AdamW - ranks equal, == one process on the global batch."""
+    import numpy as np
+    import pokemon_sprite_generator_amd.unet as U
+    old = U.ATTN_DROPOUT
+    try:
+        st, out = _full_step(False, slice(0, 4), "fp32")
+        ref_loss = float(out["loss"].item())
+        ref_path = str(tmp_path / "ref_grads.npy")
+        np.save(ref_path, st.arena.flat.detach().cpu().numpy())
+        numel = int(st.arena.numel)
+        st.close()
+        del st, out
+        torch.cuda.empty_cache()
+    finally:
+        U.ATTN_DROPOUT = old
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_full_worker, args=(r, 2, port, q, bucket_dtype, ref_path)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=900) for _ in procs], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+    for r in res:
+        assert isinstance(r[1], dict), r[1]
+    a, b = res[0][1], res[1][1]
+    assert a["world"] == b["world"] == 2 and a["flag"] == b["flag"] == 0 and a["steps"] == b["steps"] == 1
+    # the whole 2.56 GB arena crosses the ranks once per step, in 64+ MiB buckets
+    assert a["numel"] == numel and N_PARAMS <= numel <= N_PARAMS + 8 * 478
+    assert a["bytes"] == (4 if bucket_dtype == "fp32" else 2) * numel
+    # (a bucket closes with the parameter that takes it past 64 MiB, and the big 3x3 weights are 59 MB each: 27 buckets of 64-123 MiB)
+    assert 20 <= a["buckets"] <= 40 and a["buckets"] == b["buckets"], a["buckets"]
+    # overlap really happens: every bucket but (at most) the last left from a bucket-ready callback, before finish()
+    assert a["early"] >= a["buckets"] - 1 and b["early"] >= b["buckets"] - 1, (a["early"], b["early"], a["buckets"])
+    # ranks hold bit-identical averaged gradients and took the bit-identical parameter update
+    assert a["grad_digest"] == b["grad_digest"], "ranks disagree after the all-reduce"
+    assert a["param_digest"] == b["param_digest"], "ranks took different updates"
+    # == single process on the global batch (shards are per-sample independent; only summation order / bucket rounding differ)
+    bar_max, bar_bucket = (1e-4, 1e-3) if bucket_dtype == "fp32" else (8e-3, 8e-3)
+    assert a["err_max"] < bar_max and b["err_max"] < bar_max, (a["err_max"], b["err_max"])
+    assert a["worst_bucket"] < bar_bucket, a["worst_bucket"]
+    assert abs(0.5 * (a["loss"] + b["loss"]) - ref_loss) < 2e-5 * max(1.0, abs(ref_loss))
+
+
+def test_bench_rehearsal_two_ranks_one_gpu():
+    """`python bench.py --gpus 2 --rehearse` through the real launch_ranks path (parent never touches the GPU, one worker per
+    rank, rendezvous, rank-0 JSON relay): what the driver runs at N = 8, on the one GPU this box has."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rehearse", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=1500, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["nccl_world_size"] == 2 and j["collective_backend"] == "gloo"
+    assert j["config"]["global_batch"] == 2 * j["config"]["per_gpu_batch"] and j["config"]["parallelism"] == "dp2"
+    assert j["allreduce_bytes_per_step"] >= 4 * N_PARAMS
+    assert j["allreduce_buckets_launched_during_backward"] >= j["allreduce_buckets"] - 1
+    assert j["nan_flag"] == 0 and j["final_loss"] > 0 and j["value"] > 0
+    assert "roofline" in j and "rehearsal" in j

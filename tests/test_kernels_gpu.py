@@ -269,27 +269,39 @@ def test_conv_fwd_dgrad_wgrad(psg, dtype, B, H, Cin, Cout, ks, stride):
     assert maxrel(from_cl(resd.grad.cpu()), res.grad) < tol, "d residual"
 
 
-@pytest.mark.parametrize("B,H,Cin,Cout", [(256, 14, 64, 128), (512, 7, 128, 128), (72, 27, 64, 256), (2048, 4, 64, 128)])
+@pytest.mark.parametrize("B,H,Cin,Cout", [(256, 14, 64, 128), (512, 7, 128, 128), (72, 27, 64, 256), (2048, 4, 64, 128),
+                                          (256, 14, 64, 320), (72, 27, 128, 320)])
 def test_conv3x3_large_tiles(psg, B, H, Cin, Cout):
     """Shapes large enough for the tile chooser to pick the 128x128 / 128x160 tiles the benchmark runs on (the small
-    parity cases above mostly take 64x64): bf16 forward and data gradient against a CPU fp32 convolution of the same
-    bf16 operands, for every map width of the U-Net (27, 14, 7, 4)."""
+    parity cases above mostly take 64x64): bf16 forward, data gradient AND weight / bias gradient against a CPU fp32
+    convolution of the same bf16 operands, for every map width of the U-Net (27, 14, 7, 4).  The Cout = 320 cases take the
+    160-row weight-gradient tile at M = 50 176 / 52 488 pixels with a multi-slab split-K (the benchmark's regime)."""
     from pokemon_sprite_generator_amd import ops
     dtype = torch.bfloat16
     name = f"halo{B}.{H}.{Cin}.{Cout}"
     x = _q(h((B, Cin, H, H), name + "x", 1.2), dtype).requires_grad_(True)
     w = _q(h((Cout, Cin, 3, 3), name + "w", math.sqrt(3.0 / (Cin * 9))), dtype).requires_grad_(True)
-    b = h((Cout,), name + "b", 0.2)
+    b = h((Cout,), name + "b", 0.2).requires_grad_(True)
     ref = F.conv2d(x, w, b, padding=1)
     gy = _q(h(tuple(ref.shape), name + "gy", 1.0), dtype)
     ref.backward(gy)
     xd = to_cl(x.detach(), dtype).to(DEV).requires_grad_(True)
-    wd = w.detach().to(DEV)
-    y = ops.conv2d(xd, wd, b.to(DEV))
-    y.backward(to_cl(gy, dtype).to(DEV))
-    tol = TOL[dtype]
-    assert maxrel(from_cl(y.cpu()), ref.detach()) < tol, "forward"
-    assert maxrel(from_cl(xd.grad.cpu()), x.grad) < tol, "dgrad"
+    for layout in ("oihw", "ohwi"):                 # torch-contiguous weights, and the parameter arena's channels_last order
+        wd = w.detach().to(DEV)
+        if layout == "ohwi":
+            wd = wd.contiguous(memory_format=torch.channels_last)
+        wd = torch.nn.Parameter(wd)
+        bd = torch.nn.Parameter(b.detach().to(DEV))
+        xd.grad = None
+        y = ops.conv2d(xd, wd, bd)
+        y.backward(to_cl(gy, dtype).to(DEV))
+        tol = TOL[dtype]
+        assert maxrel(from_cl(y.cpu()), ref.detach()) < tol, "forward"
+        assert maxrel(from_cl(xd.grad.cpu()), x.grad) < tol, "dgrad"
+        # fp32 accumulation of exact bf16 products: only the summation order differs from the CPU's
+        assert maxrel(wd.grad.cpu(), w.grad) < 1e-4, f"wgrad ({layout})"
+        assert rel_l2(wd.grad.cpu(), w.grad) < 1e-5, f"wgrad rel-L2 ({layout})"
+        assert maxrel(bd.grad.cpu(), b.grad) < 1e-4, f"bias gradient ({layout})"
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

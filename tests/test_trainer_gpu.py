@@ -257,3 +257,87 @@ def test_graphed_train_step_equals_eager(psg):
         b.close()
     finally:
         ops.SeedSource.disable()
+
+
+class _Recorder:
+    """TensorBoard writer stub: keeps what the trainer logs."""
+
+    def __init__(self):
+        self.images, self.scalars = [], []
+
+    def add_scalar(self, tag, value, step):
+        self.scalars.append((tag, float(value), int(step)))
+
+    def add_image(self, tag, img, step):
+        self.images.append((tag, img.detach().cpu(), int(step)))
+
+    def close(self):
+        pass
+
+
+def test_trainer_seam_without_vae_stubs(psg, tmp_path):
+    """The production branch of the seam (reference improved_diffusion_trainer.py:150-225, 357-358, 571-615) with everything
+    that is in scope REAL: the trainer loads a stage-1-shaped checkpoint ({'vae_state_dict': encoder.* / decoder.*}) into
+    this package's own frozen VAEEncoder / VAEDecoder, encodes 215x215 images to the latents the U-Net trains on, and
+    `generate_samples` runs ddpm_sample -> VAEDecoder -> images in [0, 1] -> writer.  Only the BERT text encoder and the
+    data loaders (out of scope) are injected."""
+    from pokemon_sprite_generator_amd.vae import PokemonVAE, VAEDecoder, VAEEncoder
+    torch.manual_seed(0)
+    vae = PokemonVAE(latent_dim=8, text_dim=256)
+    sd = hashgen.fill_unet_state({k: tuple(v.shape) for k, v in vae.state_dict().items()}, 91, "stress")
+    ck_path = tmp_path / "vae_best_model.pth"
+    torch.save({"vae_state_dict": sd, "epoch": 3}, ck_path)
+
+    def batch(i, n=2):
+        img = torch.rand(n, 3, 215, 215, generator=torch.Generator().manual_seed(500 + i)) * 2 - 1
+        return {"image": img, "full_description": [f"sprite {i}-{j}" for j in range(n)]}
+    loaders = {"train": [batch(0), batch(1)], "val": [batch(7, n=5)], "test": []}
+    cfg = _config(tmp_path, epochs=1)
+    cfg["training"]["sample_every"] = 1
+    tr = psg.ImprovedDiffusionTrainer(cfg, str(ck_path), "seam", components={"text_encoder": _TextStub(), "data_loaders": loaders},
+                                      compute_dtype=torch.bfloat16)
+    assert isinstance(tr.vae_encoder, VAEEncoder) and isinstance(tr.vae_decoder, VAEDecoder)
+    assert tr.vae_encoder.compute_dtype == torch.float32 and tr.vae_decoder.compute_dtype == torch.float32     # frozen VAE: fp32 like the reference
+    assert all(not p.requires_grad for p in tr.vae_encoder.parameters()) and not tr.vae_encoder.training
+    assert torch.equal(tr.vae_encoder.mu_proj.weight.cpu(), sd["encoder.mu_proj.weight"])
+    assert torch.equal(tr.vae_decoder.block3_attn.k.weight.cpu(), sd["decoder.block3_attn.k.weight"])
+
+    # latents the trainer trains on == VAEEncoder called directly on the same images (same eps stream)
+    direct = VAEEncoder(3, 8, compute_dtype=torch.float32)
+    direct.load_state_dict({k[8:]: v for k, v in sd.items() if k.startswith("encoder.")})
+    direct = direct.to(DEV).eval()
+    b0 = loaders["train"][0]
+    torch.manual_seed(42)
+    lat_tr, text_tr, pre = tr._encode(b0)
+    torch.manual_seed(42)
+    lat_direct = direct(b0["image"].to(DEV))[0]
+    assert lat_tr.shape == (2, 8, 27, 27) and torch.equal(lat_tr, lat_direct)
+    assert int(pre.item()) == 0 and text_tr.shape == (2, 32, 256)
+
+    rec = _Recorder()
+    tr.writer = rec
+    tr.train()                               # 1 epoch: 2 train batches, 1 val batch, generate_samples(0), checkpoint
+    assert tr.optimizer.steps_done() == 2
+    # generate_samples: first 8 descriptions of the first val batch (it has 5), 4 at a time (:571-615)
+    assert len(rec.images) == 5, [t for t, _, _ in rec.images]
+    for tag, img, step in rec.images:
+        assert tag.startswith("Diffusion Generated/Sample_") and step == 0
+        assert img.shape == (3, 215, 215) and bool(torch.isfinite(img).all())
+        assert float(img.min()) >= 0.0 and float(img.max()) <= 1.0
+    assert len({float(img.double().sum()) for _, img, _ in rec.images}) == 5          # five different samples, not one repeated
+    assert any(t == "Diffusion Val/Loss" for t, _, _ in rec.scalars)
+    # the decoder the trainer used == the VAEDecoder called directly on the same latent
+    dec = VAEDecoder(8, 256, 3, compute_dtype=torch.float32)
+    dec.load_state_dict({k[8:]: v for k, v in sd.items() if k.startswith("decoder.")})
+    dec = dec.to(DEV).eval()
+    te = _TextStub()(b0["full_description"]).float()
+    assert torch.equal(tr.vae_decoder(lat_tr, te), dec(lat_tr, te))
+    tr.stepper.close()
+
+
+def test_trainer_partial_components_and_missing_checkpoint(psg, tmp_path):
+    """components= may inject any subset; a missing stage-1 checkpoint is an error exactly when the frozen VAE encoder would
+    have to come from it."""
+    cfg = _config(tmp_path, epochs=1)
+    with pytest.raises(FileNotFoundError):
+        psg.ImprovedDiffusionTrainer(cfg, str(tmp_path / "nope.pth"), "x", components={"text_encoder": _TextStub(), "data_loaders": _loaders()})
