@@ -29,6 +29,7 @@ struct WgP {
     int M, Q, taps;
     int rtiles, qtiles, splits, steps_per_split;   // steps of BKP pixels
     int BR;                                        // output rows (co) per tile: 128, or 160 = exact tiling of Cout = 320
+    int wide;                                      // 1: wgrad_wide_kernel (128 x 256 tile, 32-pixel K steps)
     float inv_HoWo, inv_Wo;
     uint32_t x_bytes, dy_bytes;
 };
@@ -380,6 +381,220 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Wide tile (round 3): 128 co x 256 q per 256-thread workgroup, K step of 32 pixels, each wave 64 co x 128 q = 4 x 8 MFMA
+// tiles.  What bounds the 128 x 128 x 64 kernel above was measured by ablation: with
+// the MFMAs removed the operand staging alone (LDS-DMA from L2 + fragment reads) takes as long as the MFMAs alone, the two
+// overlap only partly, and the staging runs at the ~15 TB/s (58 GB/s per CU) the L2 -> LDS path delivers - issuing the DMA
+// instructions costs nothing (out-of-range pieces: no change).  The lever is bytes per FLOP: this tile moves 24 KB per
+// 2.1 MFLOP instead of 32 KB, with 25 % fewer DMA pieces and transposing fragment reads per MFMA: +9..18 % on the layers it
+// takes (same-box A/B).  bf16, stride-1 geometries (GEOM 1 / 2) only; still two workgroups per CU (48 KB of LDS, 234 registers).
+// X tile [32 px][256 q]: 512-byte rows = two bank periods, so all rows of a transposed fragment read would hit the same
+// banks: chunk index XOR ((px & 3) << 2) | ((px >> 3) & 1) << 1 spreads the 8 rows of a half-wave (px = q4 + 8 g') over
+// the eight 32-byte bank windows; the LDS row of pixel px is (b4, b2, b3, b1, b0) of its index so that the key is the
+// same in all four staging passes (one (tap, ci) decode per lane, not four).
+// dY tile [32 px][128 co]: 256-byte rows with the 128 x 128 kernel's key.
+// Measured and dropped on this path (same box): a 160 x 256 variant for Cout = 320 (80 x 128 per wave, 160 accumulator
+// registers, four X fragments live and re-filled behind their MFMAs: -3 % against the 160 x 128 x 64 tiles it would replace),
+// a ring of three stages (72 KB, still two workgroups per CU: +-0 - the
+// kernel is not waiting on latency), a 320 x 256 tile on 512 threads (one workgroup per CU, ring of three 40 KB stages,
+// 2.3x fewer bytes per FLOP than 128 x 128: +10 % on 14x14 1280->640, -5 % elsewhere - its eight waves run in lockstep
+// between workgroup barriers, and its MFMA-only ablation is already slower than this kernel's), and that tile with the two
+// halves of the workgroup staggered by one phase (SIMD partners alternate fragment reads and MFMAs: slower still).
+template <int GEOM>
+__global__ __launch_bounds__(256, 2) void wgrad_wide_kernel(const WgP p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int CH = 8, BKP = 32, BR = 128, BQ = 256, ESZ = 2;
+    constexpr int NR = BR / 32;                                     // dY fragments per wave
+    constexpr int AROWB = BR * ESZ, BROWB = BQ * ESZ;              // 256, 512
+    constexpr int NPA = 2, NPB = 4, PASS_BYTES = 4096;
+    constexpr int AREG = NPA * PASS_BYTES, BTILE = BKP * BROWB;    // 8 KB, 16 KB
+    constexpr int STAGE = AREG + BTILE;
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [buf][dY tile | X tile]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave & 1, wc = wave >> 1;
+    int lid;
+    {
+        const int nb = gridDim.x, b0 = blockIdx.x;
+        const int q = nb >> 3, r = nb & 7, xcd = b0 & 7;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b0 >> 3);
+    }
+    const int tiles = p.rtiles * p.qtiles;
+    const int split = lid / tiles;
+    const int tix = lid - split * tiles;
+    const int rt = tix % p.rtiles, qt = tix / p.rtiles;
+    const int co0 = rt * BR, q0 = qt * BQ;
+
+    const int step0 = split * p.steps_per_split;
+    const int total_steps = (p.M + BKP - 1) / BKP;
+    int nsteps = total_steps - step0;
+    if (nsteps > p.steps_per_split) nsteps = p.steps_per_split;
+
+    constexpr uint32_t OOB = 0x80000000u;
+    const u32x4 yrs = make_rsrc(p.dy, p.dy_bytes);
+    const int ldxB = (int)p.ldx * ESZ, lddyB = (int)p.lddy * ESZ;
+    // dY staging: pass j = pixels 16 j + srA, one linear offset + a uniform pass stride
+    const int srA = tid >> 4, pcA = tid & 15;
+    const int lcA = pcA ^ (((srA & 3) << 2) | ((srA >> 2) & 3));
+    const int a_co = co0 + lcA * CH;
+    const bool a_ok = a_co < p.Cout;
+    int g_mA = step0 * BKP + srA;
+    int g_a = (g_mA * (int)p.lddy + a_co) * ESZ;
+    // X staging: pass j = pixels pxB + 16 (j >> 1) + 4 (j & 1) (LDS rows 8 j + srB)
+    const int srB = tid >> 5, pcB = tid & 31;
+    const int lcB = pcB ^ (((srB & 3) << 2) | (((srB >> 2) & 1) << 1));
+    const int pxB = ((srB >> 2) << 3) | (srB & 3);
+    const int b_q = q0 + lcB * CH;
+    const bool b_ok = b_q < p.Q;
+    const int b_tap = b_ok ? b_q / p.Cin : 0;
+    const int b_ci = b_q - b_tap * p.Cin;
+    const int b_kh = b_tap / p.ks, b_kw = b_tap - b_kh * p.ks;
+    const int HoWo = p.Ho * p.Wo;
+    const int ho_lo = max(0, p.pad - b_kh), wo_lo = max(0, p.pad - b_kw);
+    const int ho_hi = min(p.Ho - 1, p.Hi - 1 + p.pad - b_kh), wo_hi = min(p.Wo - 1, p.Wi - 1 + p.pad - b_kw);
+    const bool b_in = b_ok && ho_hi >= ho_lo && wo_hi >= wo_lo;
+    const unsigned w_rng = (unsigned)(wo_hi - wo_lo);
+    const int rm_lo = ho_lo * p.Wo;
+    const unsigned rm_rng = (unsigned)((ho_hi + 1) * p.Wo - 1 - rm_lo);
+    typedef __attribute__((address_space(3))) char* lds_ptr_t;
+    const uint32_t lds_wave = (uint32_t)(size_t)(lds_ptr_t)smem + (uint32_t)__builtin_amdgcn_readfirstlane(wave) * 1024u;
+    // the tap shift is folded into a descriptor whose base sits pad rows + pad pixels BEFORE x, so the per-lane offset stays
+    // >= 0 (taps that would read below x are never valid)
+    int g_mB = step0 * BKP + pxB;
+    const int g_shift = (p.pad * p.Wi + p.pad) * ldxB;
+    const u32x4 xrs_g = make_rsrc(reinterpret_cast<const char*>(p.x) - g_shift, p.x_bytes + (uint32_t)g_shift);
+    int g_b = g_mB * ldxB + (b_kh * p.Wi + b_kw) * ldxB + b_ci * ESZ;
+    const int st_rm = BKP % HoWo, st_wo = BKP % p.Wo;
+    int g_rm[NPB], g_wo[NPB];
+#pragma unroll
+    for (int j = 0; j < NPB; ++j) {
+        g_rm[j] = (g_mB + 16 * (j >> 1) + 4 * (j & 1)) % HoWo;
+        g_wo[j] = g_rm[j] % p.Wo;
+    }
+    const int a_step = BKP * lddyB, b_step = BKP * ldxB;
+    auto load_tiles = [&](int buf) {
+        const uint32_t adst = lds_wave + (uint32_t)buf * STAGE;
+        const uint32_t bdst = adst + AREG;
+#pragma unroll
+        for (int j = 0; j < NPA; ++j) {
+            const bool m_ok = g_mA < p.M - 16 * j;
+            const uint32_t aoff = (m_ok && a_ok) ? (uint32_t)g_a : OOB;
+            lds_dma16s(yrs, adst + j * PASS_BYTES, aoff, (uint32_t)(16 * j * lddyB));
+        }
+#pragma unroll
+        for (int j = 0; j < NPB; ++j) {
+            const int po = 16 * (j >> 1) + 4 * (j & 1);
+            bool ok = b_in && g_mB < p.M - po;
+            if constexpr (GEOM == 1) {
+                ok = ok && (unsigned)(g_rm[j] - rm_lo) <= rm_rng && (unsigned)(g_wo[j] - wo_lo) <= w_rng;
+                int rm = g_rm[j] + st_rm; rm -= rm >= HoWo ? HoWo : 0; g_rm[j] = rm;
+                int wo = g_wo[j] + st_wo; wo -= wo >= p.Wo ? p.Wo : 0; g_wo[j] = wo;
+            }
+            const uint32_t boff = ok ? (uint32_t)g_b : OOB;
+            lds_dma16s(xrs_g, bdst + j * PASS_BYTES, boff, (uint32_t)(po * ldxB));
+        }
+        g_mA += BKP; g_mB += BKP; g_a += a_step; g_b += b_step;
+    };
+
+    typedef float AccT __attribute__((ext_vector_type(4)));
+    AccT acc[NR][8];
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+    // bias gradient = column sums of the dY tile, from the waves of tile column 0: one MFMA per dY fragment against a ones
+    // operand, as in the 128 x 128 kernel.  (The tiles that carry it must not run longer than the others - a launch is often
+    // ONE round of workgroups: per-lane VALU sums of the fragments, 80 operations per K step, cost 7x7 1280->1280 11 %.)
+    const bool do_bias = p.bws != nullptr && qt == 0 && wc == 0;
+    AccT accb[NR];
+#pragma unroll
+    for (int i = 0; i < NR; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) accb[i][e] = 0.f;
+
+    // fragment read addresses (byte offsets inside a stage): lane -> (group g, row q4 of the 4 x 16 block, 4-column piece p4)
+    const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
+    // dY image keys of rows 8g+q4 and 8g+4+q4
+    const int keyA0 = (q4 << 2) | ((2 * g) & 3), keyA1 = (q4 << 2) | ((2 * g + 1) & 3);
+    const int rowa = (8 * g + q4) * AROWB + 8 * (p4 & 1);
+    const int chA = wr * (BR / 16) + (p4 >> 1);
+    const int keyB = (q4 << 2) | ((g & 1) << 1);                                                    // both rows of the X image
+    const int rowb = AREG + (((g >> 1) << 4) | ((g & 1) << 2) | q4) * BROWB + 8 * (p4 & 1);   // LDS row (b4, 0, b3, b1 b0); second read + 8 rows
+    const int chB = wc * 16 + (p4 >> 1);
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    auto rd_b = [&](const char* sb, int j) {
+        const char* b = sb + rowb + (((chB + 2 * j) ^ keyB) << 4);
+        s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b));
+        s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b + 8 * BROWB));
+        s16x8 bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        return *reinterpret_cast<bf16x8*>(&bv);
+    };
+
+    if (nsteps > 0) load_tiles(0);
+    wait_vmcnt<0>();
+    __syncthreads();
+    for (int st = 0; st < nsteps; ++st) {
+        const int buf = st & 1;
+        if (st + 1 < nsteps) load_tiles(buf ^ 1);
+        const char* sb = smem + buf * STAGE;
+        bf16x8 af[NR];
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+            s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sb + rowa + (((chA + 2 * i) ^ keyA0) << 4)));
+            s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sb + rowa + 4 * AROWB + (((chA + 2 * i) ^ keyA1) << 4)));
+            s16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+            af[i] = *reinterpret_cast<bf16x8*>(&av);
+        }
+        bf16x8 bf[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bf[j] = rd_b(sb, j);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        if (do_bias) {
+            const bf16_t one = (bf16_t)1.0f;
+            const bf16x8 ones = {one, one, one, one, one, one, one, one};
+#pragma unroll
+            for (int i = 0; i < NR; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, accb[i], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        wait_vmcnt<0>();                   // AFTER the MFMA phase: the DMA of the next tile overlapped it
+        __syncthreads();
+    }
+
+    float* wsb = p.ws + (int64_t)split * p.Cout * p.Q;
+    const int l16 = lane & 15, kq = lane >> 4;
+    if (do_bias && l16 == 0) {             // column 0 of the ones-product holds the sums
+        float* bw = p.bws + (int64_t)split * p.Cout;
+#pragma unroll
+        for (int i = 0; i < NR; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wr * (BR / 2) + i * 16 + 4 * kq + r;
+                if (co < p.Cout) bw[co] = accb[i][r] * p.scale;
+            }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int q = q0 + wc * 128 + j * 16 + l16;
+        if (q >= p.Q) continue;
+#pragma unroll
+        for (int i = 0; i < NR; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wr * (BR / 2) + i * 16 + 4 * kq + r;
+                if (co < p.Cout) wsb[(int64_t)co * p.Q + q] = acc[i][j][r] * p.scale;
+            }
+        }
+    }
+#endif
+}
+
 // dw[co][ci][tap] (+)= sum_s ws[s][co][tap*Cin + ci]; one block per (co, 256-ci chunk), LDS transpose
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Cin, int taps,
                                     int splits, int accumulate) {
@@ -433,10 +648,11 @@ __global__ void wgrad_sum_kernel(const float* __restrict__ ws, float* __restrict
 }
 
 static void wgrad_plan(const psg_wgrad_desc* d, WgP& p) {
-    const int BKP = d->dtype == PSG_BF16 ? 64 : 32;
+    int BKP = d->dtype == PSG_BF16 ? 64 : 32;
     p.M = d->B * d->Ho * d->Wo;
     p.taps = d->ksize * d->ksize;
     p.Q = p.taps * d->Cin;
+    p.wide = 0;
     {
         // 160-row tiles where they tile Cout exactly and 128 does not (Cout = 320: 2 tiles instead of 2.5 -> 3)
         static int off = -1;
@@ -444,15 +660,25 @@ static void wgrad_plan(const psg_wgrad_desc* d, WgP& p) {
         const bool same = d->stride == 1 && d->Hi == d->Ho && d->Wi == d->Wo;
         p.BR = (!off && d->dtype == PSG_BF16 && same && d->Cout % 160 == 0 && d->Cout % 128 != 0) ? 160 : 128;
     }
+    {
+        // wide (128 x 256) tiles where the 256-column grid wastes < 5 % of the q axis (PSG_WGRAD_WIDE=0: off, A/B runs)
+        static int off = -1;
+        if (off < 0) { const char* e = getenv("PSG_WGRAD_WIDE"); off = (e && atoi(e) == 0) ? 1 : 0; }
+        const bool same = d->stride == 1 && d->Hi == d->Ho && d->Wi == d->Wo;
+        const int64_t q256 = ((int64_t)p.Q + 255) / 256 * 256;
+        // ... and only where the narrow grid has >= 200 tiles: below that the wide grid leaves the chip to split-K alone (7x7 1280->1280 1x1: 100 narrow tiles, 53 -> 61 us wide; 1280->2560: 200 tiles, 99 -> 90 us)
+        const int64_t tiles128 = (int64_t)((d->Cout + 127) / 128) * ((p.Q + 127) / 128);
+        if (!off && d->dtype == PSG_BF16 && same && p.BR == 128 && q256 * 100 <= (int64_t)p.Q * 105 && tiles128 >= 200) { p.wide = 1; BKP = 32; }
+    }
+    const int kSlots = 512;
     p.rtiles = (d->Cout + p.BR - 1) / p.BR;
-    p.qtiles = (p.Q + 127) / 128;
+    p.qtiles = p.wide ? (p.Q + 255) / 256 : (p.Q + 127) / 128;
     const int total_steps = (p.M + BKP - 1) / BKP;
     const int tiles = p.rtiles * p.qtiles;
     // Split-K choice by a makespan model: 2 workgroups (64 KB LDS each) per CU x 256 CUs = 512 slots; a launch runs
     // in ceil(blocks/512) rounds of (steps_per_split + fixed prologue/epilogue) K steps, and every extra split adds
     // one slab of traffic to the deterministic sum pass.  Picking the split count that merely "fills the chip"
     // leaves e.g. 1035 blocks = 2.02 rounds (a third of the time on 11 stragglers); this picks 966 or 483 instead.
-    const int kSlots = 512;
     const double step_us = (d->dtype == PSG_BF16 ? 1.05 : 8.0) * (p.BR == 160 ? 1.25 : 1.0), fixed_steps = 6.0;
     const double slab_us = (double)d->Cout * p.Q * 4.0 / 4.0e6;          // one fp32 slab through HBM at ~4 TB/s
     const bool native = d->dw_layout == PSG_W_OHWI || p.taps == 1;
@@ -469,6 +695,11 @@ static void wgrad_plan(const psg_wgrad_desc* d, WgP& p) {
         const bool direct = native && sp == 1 && !d->accumulate;
         const double cost = rounds * (sps + fixed_steps) * step_us + (direct ? 0.0 : (sp + 1.0) * slab_us + 3.0);
         if (cost < best - 1e-9) { best = cost; best_sps = sps; }
+    }
+    {
+        static int force = -2;                             // PSG_WGRAD_SPLITS=n pins the split count (kernel experiments)
+        if (force == -2) { const char* e = getenv("PSG_WGRAD_SPLITS"); force = e ? atoi(e) : -1; }
+        if (force > 0) best_sps = (total_steps + force - 1) / force;
     }
     p.steps_per_split = best_sps;
     p.splits = (total_steps + p.steps_per_split - 1) / p.steps_per_split;
@@ -491,6 +722,8 @@ int psg_wgrad_init_attrs(void) {
 #undef PSG_WG_ATTR
     PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<bf16_t, 1, 160>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (320 + 256)));
     PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<bf16_t, 2, 160>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (320 + 256)));
+    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wide_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (8192 + 16384)));
+    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wide_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (8192 + 16384)));
     return PSG_OK;
 }
 
@@ -551,12 +784,21 @@ int psg_conv_wgrad(const psg_wgrad_desc* d, psg_stream_t stream) {
     const int grid = p.rtiles * p.qtiles * p.splits;
     hipStream_t s = (hipStream_t)stream;
     {
+        static int dbg = -1;                               // PSG_WGRAD_DEBUG=1: print the plan of every launch
+        if (dbg < 0) { const char* e = getenv("PSG_WGRAD_DEBUG"); dbg = e ? atoi(e) : 0; }
+        if (dbg) fprintf(stderr, "psg wgrad: M=%d Cout=%d Q=%d wide=%d BR=%d tiles=%dx%d splits=%d steps/split=%d grid=%d direct=%d\n", p.M, d->Cout,
+                         p.Q, p.wide, p.BR, p.rtiles, p.qtiles, p.splits, p.steps_per_split, grid, (int)direct);
+    }
+    {
         ProfScope prof(PROF_WGRAD, 2.0 * (double)p.M * (double)p.Cout * (double)p.Q, s);
         const int geom = d->stride != 1 || d->Hi != d->Ho || d->Wi != d->Wo ? 0 : (d->ksize == 1 ? 2 : 1);
 #define PSG_WG_LAUNCH(G)                                                                                               \
         if (d->dtype == PSG_BF16) hipLaunchKernelGGL((wgrad_kernel<bf16_t, G>), dim3(grid), dim3(256), 4 * 64 * 256, s, p); \
         else hipLaunchKernelGGL((wgrad_kernel<float, G>), dim3(grid), dim3(256), 4 * 32 * 512, s, p);
-        if (p.BR == 160) {
+        if (p.wide) {
+            if (geom == 1) hipLaunchKernelGGL((wgrad_wide_kernel<1>), dim3(grid), dim3(256), 2 * (8192 + 16384), s, p);
+            else hipLaunchKernelGGL((wgrad_wide_kernel<2>), dim3(grid), dim3(256), 2 * (8192 + 16384), s, p);
+        } else if (p.BR == 160) {
             if (geom == 1) hipLaunchKernelGGL((wgrad_kernel<bf16_t, 1, 160>), dim3(grid), dim3(256), 2 * 64 * (320 + 256), s, p);
             else hipLaunchKernelGGL((wgrad_kernel<bf16_t, 2, 160>), dim3(grid), dim3(256), 2 * 64 * (320 + 256), s, p);
         } else if (geom == 0) { PSG_WG_LAUNCH(0) } else if (geom == 1) { PSG_WG_LAUNCH(1) } else { PSG_WG_LAUNCH(2) }

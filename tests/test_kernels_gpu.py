@@ -645,3 +645,52 @@ def test_conv_epilogue_kinds_bitwise(psg, M, K, N):
         assert torch.equal(ya, yb), f"y differs for {kw}"
         assert torch.equal(pa, pb), f"preact differs for {kw}"
         assert torch.isfinite(ya.float()).all()
+
+
+# (B, H, Cin, Cout, ks): shapes whose (tap, ci) axis tiles by 256 columns with < 5 % waste, so the weight gradient takes the
+# wide 128 x 256 tile (32-pixel K steps): exact tiling, a q tail (Cin 248: 2232 of 2304 columns), a Cout tail (192 = 1.5
+# row tiles), pixel counts that are not multiples of 32, the three map widths with borders, pointwise layers, batch large
+# enough for several splits, and a row stride wider than Cin (a concat slice)
+WIDE_CASES = [(3, 14, 256, 128, 3), (5, 7, 248, 192, 3), (2, 27, 256, 128, 3), (37, 4, 512, 256, 3), (3, 9, 1280, 128, 1),
+              (64, 14, 256, 256, 3), (1, 5, 256, 64, 3), (130, 7, 768, 128, 1),
+              # a 1 x 1 layer with 30 row tiles, and Cout = 320 (stays on the 160 x 128 tiles)
+              (5, 14, 1280, 3840, 1), (9, 27, 256, 320, 3)]
+
+
+@pytest.mark.parametrize("layout", ["oihw", "ohwi"])
+@pytest.mark.parametrize("B,H,Cin,Cout,ks", WIDE_CASES)
+def test_wgrad_wide_tiles(psg, B, H, Cin, Cout, ks, layout):
+    from pokemon_sprite_generator_amd import ops
+    dtype = torch.bfloat16
+    pad = 1 if ks == 3 else 0
+    name = f"wide{B}.{H}.{Cin}.{Cout}.{ks}"
+    x = _q(h((B, Cin, H, H), name + "x", 1.2), dtype)
+    w = _q(h((Cout, Cin, ks, ks), name + "w", math.sqrt(3.0 / (Cin * ks * ks))), dtype).requires_grad_(True)
+    b = h((Cout,), name + "b", 0.2).requires_grad_(True)
+    ref = F.conv2d(x, w, b, padding=pad)
+    gy = _q(h(tuple(ref.shape), name + "gy", 1.0), dtype)
+    ref.backward(gy)
+    # x as a slice of a wider buffer (row stride Cin + 64), like the decoder's concat halves
+    wide_buf = torch.zeros((B, H, H, Cin + 64), dtype=dtype, device=DEV)
+    wide_buf[..., :Cin] = to_cl(x, dtype).to(DEV)
+    xd = wide_buf[..., :Cin]
+    wd = w.detach().to(DEV)
+    if layout == "ohwi" and ks == 3:
+        wd = wd.contiguous(memory_format=torch.channels_last)
+    wd = torch.nn.Parameter(wd)
+    bd = torch.nn.Parameter(b.detach().to(DEV))
+    y = ops.conv2d(xd, wd, bd)
+    y.backward(to_cl(gy, dtype).to(DEV))
+    assert maxrel(wd.grad.cpu(), w.grad) < 1e-4 and rel_l2(wd.grad.cpu(), w.grad) < 1e-5, "wgrad"
+    assert maxrel(bd.grad.cpu(), b.grad) < 1e-4, "bias gradient"
+    # accumulate path (a weight used twice through a gradient sink adds into the first result)
+    from pokemon_sprite_generator_amd import GradArena
+    arena = GradArena([wd, bd])
+    arena.zero()
+    y = ops.conv2d(xd, wd, bd) + ops.conv2d(xd, wd, bd)
+    y.backward(to_cl(gy, dtype).to(DEV))
+    arena.finalize()
+    torch.cuda.synchronize()
+    assert maxrel(wd.grad.cpu(), 2 * w.grad) < 1e-4, "wgrad accumulate"
+    assert maxrel(bd.grad.cpu(), 2 * b.grad) < 1e-4, "bias accumulate"
+    arena.release()
