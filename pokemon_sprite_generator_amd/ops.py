@@ -318,8 +318,11 @@ class SideStream:
     """Second HIP stream for the weight-gradient GEMMs of backward: wgrad depends only on the saved input and dY and
     nothing else in backward depends on it, so it fills the tail waves of the data-gradient GEMM that runs next on
     the main stream (-1.5 % step time).  Used only for gradients that go to a GradSink (optim.GradArena): the arena's
-    finalize() joins the stream before anything reads the gradients.  PSG_WGRAD_STREAM=0 disables it."""
-    enabled = os.environ.get("PSG_WGRAD_STREAM", "1") != "0"
+    finalize() joins the stream before anything reads the gradients.  OFF by default since round 3 (PSG_WGRAD_STREAM=1
+    enables it): it paid -1.5 % in round 1, when the data-gradient kernels left tail waves idle; with the round-3
+    weight-gradient tiles two co-running GEMMs only take each other's CUs (same box, batch 256: 82.4 ms with the
+    stream, 81.5 without)."""
+    enabled = os.environ.get("PSG_WGRAD_STREAM", "0") != "0"
     _streams = {}
     used = False
     # Operands of the launches still in flight on the side stream.  Holding the Python reference does two things:

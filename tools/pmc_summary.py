@@ -27,7 +27,7 @@ def family(name):
         return "conv_gemm(fwd gather)" if m.group(3) in "02" else "conv_gemm(dgrad gather)"
     if "conv_gemm_kernel" in name:
         return "conv_gemm(?)"
-    if "wgrad_kernel" in name:
+    if "wgrad_kernel" in name or "wgrad_wide_kernel" in name:
         return "wgrad"
     if "attn_" in name:
         return "attention"
