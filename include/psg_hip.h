@@ -226,8 +226,14 @@ typedef struct psg_conv_desc {
                                     act'(dact_u[m,n]) (saved pre-activation) and by the same dropout mask.  Used by
                                     the FFN backward: the data gradient of its second Linear comes out already
                                     multiplied by GELU'(u) * mask of the first.  Mutually exclusive with residual. */
+    void* ws;                    /* optional split-K workspace (16-byte aligned) of ws_bytes bytes, or NULL: with at least */
+    int64_t ws_bytes;            /* psg_conv_fwd_workspace_bytes(d) bytes a launch whose tile grid would leave most of the
+                                    chip idle (small M: the sampler of improved_diffusion_trainer.py:534-567 at 64 samples,
+                                    training batches of 2-4) shares each tile's K axis among several workgroups - fp32
+                                    partial tiles, summed in fixed order by a second kernel that applies the epilogue */
 } psg_conv_desc;
 int psg_conv_fwd(const psg_conv_desc* d, psg_stream_t stream);
+int64_t psg_conv_fwd_workspace_bytes(const psg_conv_desc* d);   /* 0: the launch would not be split; < 0: bad descriptor */
 
 /* Weight gradient — convolution_backward's wgrad for the same layers.
  * dw (fp32) = sum_m dy[m,co] * x[pix(m,kh,kw), ci], stored in the parameter's own memory order:

@@ -32,6 +32,7 @@ class ConvDesc(C.Structure):
         ("ld_preact", C.c_int64), ("ld_dact", C.c_int64), ("ldw", C.c_int64),
         ("x", c_void_p), ("w", c_void_p), ("y", c_void_p), ("bias", c_void_p), ("rowadd", c_void_p),
         ("residual", c_void_p), ("preact", c_void_p), ("dact_u", c_void_p),
+        ("ws", c_void_p), ("ws_bytes", C.c_int64),
     ]
 
 
@@ -76,6 +77,7 @@ SIGNATURES = {
                               + [c_int] * 7 + [c_void_p, c_void_p]),
     "psg_groupnorm_bwd_workspace_bytes": (c_int64, [c_int, c_int]),
     "psg_conv_fwd": (c_int, [C.POINTER(ConvDesc), c_void_p]),
+    "psg_conv_fwd_workspace_bytes": (c_int64, [C.POINTER(ConvDesc)]),
     "psg_conv_wgrad": (c_int, [C.POINTER(WgradDesc), c_void_p]),
     "psg_conv_wgrad_workspace_bytes": (c_int64, [C.POINTER(WgradDesc)]),
     "psg_prep_weight": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

@@ -14,34 +14,78 @@ PSG_TILE_DECL(bf16_t, 128, 160) PSG_TILE_DECL(bf16_t, 64, 160)
 #undef PSG_TILE_DECL
 
 
-// tile choice: maximise (useful fraction of the tile grid) x (chip fill of the last wave) x (tile efficiency)
-static int choose_and_launch(const ConvP& p, int dtype, hipStream_t s) {
+// tile choice: maximise (useful fraction of the tile grid) x (chip fill of the last wave) x (tile efficiency); then, for
+// grids that leave most of the chip idle (small M: sampling, small batches), split-K on top
+struct ConvPlan { int BM, BN, splits, kt_per_split; };
+static ConvPlan conv_plan(const ConvP& p, int dtype, bool may_split) {
     const int64_t M = p.M;
-    int BM = 128, BN = 128;
-    {
-        static int force = -2;                             // PSG_CONV_TILE=0..3 pins a candidate (kernel A/B runs)
-        if (force == -2) { const char* e = getenv("PSG_CONV_TILE"); force = e ? atoi(e) : -1; }
-        const int cand[5][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 160}, {64, 160}};
-        double eff[5] = {1.0, 0.78, 0.55, 1.0, 0.70};      // measured relative MFMA efficiency of the tile shapes
-        // (a K <= 640 boost for 128x64 - three resident workgroups hiding the short loop ends - paid before the epilogue was
-        //  specialised per kind; since then 128x128 wins those layers by 10 %: gemm_direct.py)
-        if (dtype != PSG_BF16 || p.ntap > 0) eff[3] = eff[4] = 0.0;   // 160 = 2 x 5 x 16: only the 16x16x32 bf16 tiles divide it
-        const double slots = 512.0;                        // resident workgroups on the chip (2 per CU)
-        double best = -1.0;
-        for (int c = 0; c < 5; ++c) {
-            const double tiles = (double)((M + cand[c][0] - 1) / cand[c][0]) * (double)((p.N + cand[c][1] - 1) / cand[c][1]);
-            const double useful = (double)M * p.N / (tiles * cand[c][0] * cand[c][1]);
-            const double waves = ceil(tiles / slots);
-            double score = useful * (tiles / (waves * slots)) * eff[c];
-            if (force >= 0) score = (c == force) ? 1.0 : 0.0;
-            if (score > best) { best = score; BM = cand[c][0]; BN = cand[c][1]; }
+    ConvPlan pl = {128, 128, 1, p.KT};
+    static int force = -2;                             // PSG_CONV_TILE=0..4 pins a candidate (kernel A/B runs)
+    if (force == -2) { const char* e = getenv("PSG_CONV_TILE"); force = e ? atoi(e) : -1; }
+    const int cand[5][2] = {{128, 128}, {128, 64}, {64, 64}, {128, 160}, {64, 160}};
+    double eff[5] = {1.0, 0.78, 0.55, 1.0, 0.70};      // measured relative MFMA efficiency of the tile shapes
+    // (a K <= 640 boost for 128x64 - three resident workgroups hiding the short loop ends - paid before the epilogue was
+    //  specialised per kind; since then 128x128 wins those layers by 10 %: gemm_direct.py)
+    if (dtype != PSG_BF16 || p.ntap > 0) eff[3] = eff[4] = 0.0;   // 160 = 2 x 5 x 16: only the 16x16x32 bf16 tiles divide it
+    const double slots = 512.0;                        // resident workgroups on the chip (2 per CU)
+    double best = -1.0;
+    for (int c = 0; c < 5; ++c) {
+        const double tiles = (double)((M + cand[c][0] - 1) / cand[c][0]) * (double)((p.N + cand[c][1] - 1) / cand[c][1]);
+        const double useful = (double)M * p.N / (tiles * cand[c][0] * cand[c][1]);
+        const double waves = ceil(tiles / slots);
+        double score = useful * (tiles / (waves * slots)) * eff[c];
+        if (force >= 0) score = (c == force) ? 1.0 : 0.0;
+        if (score > best) { best = score; pl.BM = cand[c][0]; pl.BN = cand[c][1]; }
+    }
+    // Split-K: when the unsplit grid fills less than ~60 % of the chip and the K loop is long enough to share.  Estimated time
+    // of (tile shape c, s splits) in K steps of a 128 x 128 tile: rounds x (steps per split + 6 of prologue / epilogue) x
+    // (tile area / efficiency) + the partial tiles' trip through memory ((s + 1) x M x N x 4 bytes at ~3 TB/s, 0.9 us per step).
+    static int nosplit = -1;
+    if (nosplit < 0) { const char* e = getenv("PSG_CONV_SPLITK"); nosplit = (e && atoi(e) == 0) ? 1 : 0; }
+    if (may_split && !nosplit && p.ntap == 0 && force < 0 && p.KT >= 16) {
+        const double tiles0 = (double)((M + pl.BM - 1) / pl.BM) * (double)((p.N + pl.BN - 1) / pl.BN);
+        if (tiles0 < 0.6 * slots || best < 0.6) {
+            auto est = [&](int c, int s) {
+                const double tiles = (double)((M + cand[c][0] - 1) / cand[c][0]) * (double)((p.N + cand[c][1] - 1) / cand[c][1]);
+                const int per = (p.KT + s - 1) / s;
+                const double rounds = ceil(tiles * s / slots);
+                const double step = (double)cand[c][0] * cand[c][1] / (128.0 * 128.0) / eff[c];
+                const double fin = s > 1 ? ((s + 1.0) * (double)M * p.N * 4.0 / 3.0e6 + 4.0) / 0.9 : 0.0;
+                return rounds * (per + 6.0) * step + fin;
+            };
+            int bc = 0;
+            for (int c = 0; c < 5; ++c) if (cand[c][0] == pl.BM && cand[c][1] == pl.BN) bc = c;
+            double tbest = est(bc, 1);
+            const int svals[9] = {2, 3, 4, 5, 6, 8, 10, 12, 16};
+            for (int c = 0; c < 5; ++c) {
+                if (eff[c] <= 0.0) continue;
+                for (int si = 0; si < 9; ++si) {
+                    const int s = svals[si];
+                    if (p.KT / s < 8) break;                       // at least 8 K steps per split
+                    if ((double)s * M * p.N * 4.0 > 256.0e6) break;   // partial tiles: <= 256 MB
+                    const double t = est(c, s);
+                    if (t < tbest * 0.9) { tbest = t; pl.BM = cand[c][0]; pl.BN = cand[c][1]; pl.splits = s; }
+                }
+            }
+            if (pl.splits > 1) { pl.kt_per_split = (p.KT + pl.splits - 1) / pl.splits; pl.splits = (p.KT + pl.kt_per_split - 1) / pl.kt_per_split; }
         }
+    }
+    return pl;
+}
+
+static int choose_and_launch(const ConvP& p0, int dtype, hipStream_t s) {
+    ConvP p = p0;
+    const ConvPlan pl = conv_plan(p, dtype, p.ws != nullptr);
+    const int BM = pl.BM, BN = pl.BN;
+    p.splits = 1; p.kt_per_split = p.KT;
+    if (pl.splits > 1 && p.ws != nullptr && (int64_t)pl.splits * p.M * p.N * 4 <= p.ws_bytes) {
+        p.splits = pl.splits; p.kt_per_split = pl.kt_per_split;
     }
     {
         static int dbg = -1;                               // PSG_CONV_DEBUG=1: print the tile chosen for every launch
         if (dbg < 0) { const char* e = getenv("PSG_CONV_DEBUG"); dbg = e ? atoi(e) : 0; }
-        if (dbg) fprintf(stderr, "psg conv: M=%d N=%d Cin=%d ks=%d tr=%d fast=%d epi_lds=%d -> tile %dx%d\n", p.M, p.N, p.Cin, p.ks, p.transposed,
-                         p.fast, p.epi_lds, BM, BN);
+        if (dbg) fprintf(stderr, "psg conv: M=%d N=%d Cin=%d ks=%d tr=%d fast=%d epi_lds=%d -> tile %dx%d splits=%d\n", p.M, p.N, p.Cin, p.ks, p.transposed,
+                         p.fast, p.epi_lds, BM, BN, p.splits);
     }
     if (BN == 160 && BM == 64) return launch_conv<bf16_t, 64, 160>(p, s);
     if (BN == 160) return launch_conv<bf16_t, 128, 160>(p, s);
@@ -74,7 +118,7 @@ int psg_conv_init_attrs(void) {
     return PSG_OK;
 }
 
-int psg_conv_fwd(const psg_conv_desc* d, psg_stream_t stream) {
+static int conv_setup(const psg_conv_desc* d, ConvP& p) {
     PSG_REQUIRE(d && d->x && d->w && d->y, PSG_ERR_ARG, "conv_fwd: null pointer");
     PSG_REQUIRE(d->dtype == PSG_F32 || d->dtype == PSG_BF16, PSG_ERR_DTYPE, "conv_fwd: dtype %d", d->dtype);
     const int CH = d->dtype == PSG_BF16 ? 8 : 4;
@@ -114,7 +158,6 @@ int psg_conv_fwd(const psg_conv_desc* d, psg_stream_t stream) {
     const int64_t Kpad = psg_kpad((int64_t)taps * d->Cin, d->dtype);
     PSG_REQUIRE(d->ldw == 0 || (d->ldw >= Kpad && d->ldw % CH == 0), PSG_ERR_SHAPE, "conv_fwd: ldw=%ld < Kpad=%ld", (long)d->ldw, (long)Kpad);
 
-    ConvP p;
     p.x = d->x; p.w = d->w; p.y = d->y; p.bias = d->bias; p.rowadd = d->rowadd; p.residual = d->residual;
     p.preact = d->preact; p.dact_u = d->dact_u;
     p.ldw = d->ldw > 0 ? d->ldw : Kpad;
@@ -144,9 +187,29 @@ int psg_conv_fwd(const psg_conv_desc* d, psg_stream_t stream) {
         PSG_REQUIRE(xb < 0x7FFFFFF0ll && wb < 0x7FFFFFF0ll, PSG_ERR_SHAPE, "conv_fwd: operand extent >= 2 GiB (x %ld B, w %ld B)", (long)xb, (long)wb);
         p.x_bytes = (uint32_t)xb; p.w_bytes = (uint32_t)wb;
     }
-
-    hipStream_t s = (hipStream_t)stream;
+    p.ws = (d->ws && aligned16(d->ws)) ? reinterpret_cast<float*>(d->ws) : nullptr;
+    p.ws_bytes = p.ws ? d->ws_bytes : 0;
+    p.splits = 1; p.kt_per_split = p.KT;
     p.ntap = 0; p.sub_h0 = p.sub_w0 = p.sub_nH = p.sub_nW = 0;
+    return PSG_OK;
+}
+
+// Bytes of workspace with which psg_conv_fwd would split the K axis of this launch over several workgroups (0: it would not -
+// large grids, stride-2 data gradients, short K).  The workspace is optional: without it (ws NULL / too small) the launch
+// runs unsplit.  Meant for small-M launches (sampling, small batches); the call costs a plan evaluation on the host.
+int64_t psg_conv_fwd_workspace_bytes(const psg_conv_desc* d) {
+    ConvP p;
+    if (conv_setup(d, p) != PSG_OK) return -1;
+    if (p.transposed && p.stride == 2 && p.fast && p.ks == 3) return 0;
+    const ConvPlan pl = conv_plan(p, d->dtype, true);
+    return pl.splits > 1 ? (int64_t)pl.splits * p.M * p.N * 4 : 0;
+}
+
+int psg_conv_fwd(const psg_conv_desc* d, psg_stream_t stream) {
+    ConvP p;
+    const int rc0 = conv_setup(d, p);
+    if (rc0) return rc0;
+    hipStream_t s = (hipStream_t)stream;
     if (p.transposed && p.stride == 2 && p.fast && p.ks == 3) {
         // Data gradient of a stride-2 conv: a result pixel (ho, wo) is reached only by the taps with
         // kh = (ho + pad) mod 2 (mod 2), same for kw - 1, 2, 2 or 4 of the 9.  One launch per parity class, each a

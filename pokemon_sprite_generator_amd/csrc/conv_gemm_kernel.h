@@ -42,6 +42,12 @@ struct ConvP {
     // j < sub_nW; only the ntap filter taps that reach them: source pixel (i + tap_dh, j + tap_dw), weight tap tap_wi
     int sub_h0, sub_w0, sub_nH, sub_nW, ntap;
     int tap_dh[4], tap_dw[4], tap_wi[4];
+    // split-K (small M: sampling, small training batches): `splits` workgroups share one output tile, each reduces
+    // kt_per_split K steps and writes its fp32 partial tile to ws[split][M][N]; conv_splitk_finish_kernel sums the partials
+    // in fixed order and applies the epilogue.  splits == 1: the kernel's own epilogue, no workspace.
+    int splits, kt_per_split;
+    float* ws;
+    int64_t ws_bytes;
 };
 
 template <typename T> struct Mma;           // 32x32 fragment path (fp32 only; bf16 uses mma16 below)
@@ -223,11 +229,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
     const int wn = wave & 1, wm = wave >> 1;
 
     // ---- XCD-aware tile id + grouped raster -------------------------------
-    int mt, nt;
+    int mt, nt, split = 0;
     {
         const int nb = gridDim.x, bid = blockIdx.x;
         const int q = nb >> 3, r = nb & 7, xcd = bid & 7;
-        const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+        if (p.splits > 1) { const int tiles = p.mtiles * p.ntiles; split = lid / tiles; lid -= split * tiles; }   // split slowest
         constexpr int GM = 8;
         const int per_group = GM * p.ntiles;
         const int g = lid / per_group, rem = lid - g * per_group;
@@ -286,8 +293,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
         }
     }
 
-    // uniform tap state of the NEXT K step to load (fast modes): chunk offset inside the tap, kh, kw
+    // this workgroup's K steps [kt0, kt1) (the whole K axis unless split-K)
+    const int kt0 = split * p.kt_per_split;
+    const int kt1 = p.splits > 1 ? min(p.KT, kt0 + p.kt_per_split) : p.KT;
+    // uniform tap state of the NEXT K step to load (fast modes): chunk offset inside the tap, kh, kw - at step kt0 of the
+    // taps-innermost walk (MODE 3: t_kh indexes the class's tap table)
     int t_c0 = 0, t_kh = 0, t_kw = 0;
+    if (p.splits > 1 && kt0 > 0) {
+        if (MODE == 3) { t_c0 = (kt0 / p.ntap) * 8; t_kh = kt0 % p.ntap; }
+        else if (MODE != 2) { const int tp = kt0 % p.taps; t_c0 = (kt0 / p.taps) * 8; t_kh = tp / p.ks; t_kw = tp - t_kh * p.ks; }
+    }
     // wave-uniform LDS byte offset of this wave's 1 KiB slot in pass 0 (rows 8*wave .. 8*wave+7)
     typedef __attribute__((address_space(3))) char* lds_ptr_t;
     const uint32_t lds_wave = (uint32_t)(size_t)(lds_ptr_t)smem + (uint32_t)__builtin_amdgcn_readfirstlane(wave) * 1024u;
@@ -424,8 +439,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
         }
     };
 
-    const int KT = p.KT;
-    load_tiles(0, 0);
+    load_tiles(kt0, 0);
     // Epilogue operands that do not depend on the GEMM (bias, residual, output-row decode) are requested NOW, right
     // behind the first tile's DMA: their latency disappears under the K loop instead of being exposed after it.
     // (A residual that aliases y is still read before this workgroup - the only writer of these rows - stores.)
@@ -458,8 +472,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
     }
     wait_vmcnt<0>();
     __syncthreads();                       // the DMA of tile 0 has landed for every wave
-    for (int kt = 0; kt + 1 < KT; ++kt) {
-        const int buf = kt & 1;
+    for (int kt = kt0; kt + 1 < kt1; ++kt) {
+        const int buf = (kt - kt0) & 1;
         // buffer buf^1 was last read in step kt-1, which every wave finished before the barrier below
         load_tiles(kt + 1, buf ^ 1);
         compute(buf);
@@ -470,6 +484,39 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
     // fetch goes out NOW and flies under the step's MFMAs.  vmcnt retires in order: issued any earlier these HBM-latency
     // loads sit in front of a tile DMA and the wait for that tile waits for them too (behind the first tile, as before,
     // they stretched every workgroup's prologue: a residual cost a K<=1280 Linear 35-50 % more than its bandwidth).
+    if (p.splits > 1) {
+        // split-K: this workgroup's share of the reduction goes out as an fp32 partial tile; the epilogue runs in the
+        // finishing kernel (fixed summation order over the splits: deterministic)
+        compute((kt1 - 1 - kt0) & 1);
+        float* wsb = p.ws + (int64_t)split * p.M * p.N;
+        if constexpr (FT16) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int mt_ = m0 + wm * WM + j * 16 + l16;
+#pragma unroll
+                for (int i = 0; i < NA; ++i) {
+                    const int n = n0 + wn * WN + i * 16 + 4 * kq;
+                    if (mt_ < p.M && n < p.N) *reinterpret_cast<f32x4*>(wsb + (int64_t)mt_ * p.N + n) = acc[i][j];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                const int mt_ = m0 + wm * WM + j * 32 + fr;
+#pragma unroll
+                for (int i = 0; i < NA; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int n = n0 + wn * WN + i * 32 + 8 * g + 4 * fh;
+                        if (mt_ < p.M && n < p.N) {
+                            const f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                            *reinterpret_cast<f32x4*>(wsb + (int64_t)mt_ * p.N + n) = v;
+                        }
+                    }
+            }
+        }
+        return;
+    }
     if constexpr (FT16) {
         // (the bias too: even as L2 hits its loads, issued behind the first tile, held every workgroup's first wait for
         //  0.5-1 us - a bias cost a K = 640 Linear 12-18 %)
@@ -490,7 +537,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
             }
         }
     }
-    compute((KT - 1) & 1);
+    compute((kt1 - 1 - kt0) & 1);
     __syncthreads();                       // every wave is done with the tile buffers: the epilogue reuses them
 
     // ---- fused epilogue: phase 1 loads every bias / residual operand of the tile, phase 2 computes and stores ----
@@ -744,14 +791,40 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
 }
 
 
+// split-K finish: y[m, n..n+3] = epilogue(sum_s ws[s][m][n..n+3]) - the run-time epilogue form (conv_value), one thread per
+// pixel and 4 channels; MODE 3 (parity-class launches) is never split, so tile pixel == y row
+template <typename T>
+__global__ __launch_bounds__(256) void conv_splitk_finish_kernel(const ConvP p) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int n4 = p.N >> 2;
+    if (idx >= (int64_t)p.M * n4) return;
+    const int m = (int)(idx / n4), n = (int)(idx - (int64_t)m * n4) << 2;
+    const int64_t slab = (int64_t)p.M * p.N;
+    const float* src = p.ws + (int64_t)m * p.N + n;
+    f32x4 v = *reinterpret_cast<const f32x4*>(src);
+    for (int s = 1; s < p.splits; ++s) v += *reinterpret_cast<const f32x4*>(src + s * slab);
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const T* resg = reinterpret_cast<const T*>(p.dact_u ? p.dact_u : p.residual);
+    const int64_t ldaux = p.dact_u ? p.lddact : p.ldres;
+    const T* rag = reinterpret_cast<const T*>(p.rowadd);
+    const int b = rag ? m / (p.Ho * p.Wo) : 0;
+    const f32x4 b4 = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : zero4;
+    const f32x4 r4 = resg ? load4<T>(resg + (int64_t)m * ldaux + n) : zero4;
+    const f32x4 a4 = rag ? load4<T>(rag + (int64_t)b * p.ldra + n) : zero4;
+    const uint64_t dseed = p.drop_seed + ((p.drop_thresh && p.seed_dev) ? *p.seed_dev : 0ull);
+    conv_emit<T>(p, m, n, v, b4, a4, r4, dseed);
+}
+
 template <typename T, int BM, int BN>
 int launch_conv(const ConvP& p, hipStream_t stream) {
     const size_t lds = (size_t)2 * (BM + BN) * 128;
     ConvP q = p;
     q.mtiles = (p.M + BM - 1) / BM;
     q.ntiles = (p.N + BN - 1) / BN;
-    const int grid = q.mtiles * q.ntiles;
+    const int grid = q.mtiles * q.ntiles * (q.splits > 1 ? q.splits : 1);
     ProfScope prof(p.transposed ? PROF_CONV_DGRAD : PROF_CONV_FWD, 2.0 * (double)p.M * (double)p.N * (double)p.taps * (double)p.Cin, stream);
+    const ConvP fin = q;                               // (the finishing kernel runs the epilogue: it keeps the operands)
+    if (q.splits > 1) { q.bias = nullptr; q.rowadd = nullptr; q.residual = nullptr; q.preact = nullptr; q.dact_u = nullptr; }
     const int mode = p.ntap > 0 ? 3 : (!p.fast ? 2 : (!p.transposed ? 0 : (p.stride == 1 ? 1 : 2)));
     if (mode == 3) {
         // (the 160-wide tiles are not built for the parity-class mode: its tap tables push the kernel past the scalar
@@ -763,6 +836,12 @@ int launch_conv(const ConvP& p, hipStream_t stream) {
     else hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 2>), dim3(grid), dim3(256), lds, stream, q);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return hip_fail(e, "conv_gemm launch");
+    if (q.splits > 1) {
+        const int64_t n = (int64_t)q.M * (q.N >> 2);
+        hipLaunchKernelGGL((conv_splitk_finish_kernel<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, fin);
+        e = hipGetLastError();
+        if (e != hipSuccess) return hip_fail(e, "conv_splitk_finish launch");
+    }
     return PSG_OK;
 }
 

@@ -246,7 +246,7 @@ class GradSink:
 
 # The two descriptors are packed with struct.pack_into into per-thread buffers (backward runs on autograd's thread) and
 # handed over as a pointer: one C call instead of ~30 ctypes field stores (8 us a launch, ~600 launches per train step).
-_CONV_FMT = struct.Struct("<13i2fiQ7q8Q")       # struct psg_conv_desc
+_CONV_FMT = struct.Struct("<13i2fiQ7q8QQq")     # struct psg_conv_desc
 _WGRAD_FMT = struct.Struct("<14ifi2q5Qq")       # struct psg_wgrad_desc
 assert _CONV_FMT.size == C.sizeof(ConvDesc) and _WGRAD_FMT.size == C.sizeof(WgradDesc)
 _tls = threading.local()
@@ -260,6 +260,15 @@ def _desc_bufs():
     return b
 
 
+_SPLITK = os.environ.get("PSG_CONV_SPLITK", "1") != "0"
+_SPLITK_MAX_OUT = 1 << 23            # M x Cout above which a launch fills the chip anyway
+
+
+class SplitKStats:
+    """How many conv / linear launches were given a split-K workspace (tests, tools)."""
+    launches = 0
+
+
 def _conv_launch(lib, dtype, x, ldx, w, ldw, y, ldy, geom, Cin, Cout, transposed=False, bias=None, rowadd=None,
                  residual=None, ld_res=0, preact=None, dact_u=None, ld_dact=0, act=ACT_NONE, alpha=1.0, drop_p=0.0, seed=0, flags=0):
     B, Hi, Wi, Ho, Wo, ks, stride, pad = geom
@@ -271,7 +280,15 @@ def _conv_launch(lib, dtype, x, ldx, w, ldw, y, ldy, geom, Cin, Cout, transposed
                         x.data_ptr(), w if isinstance(w, int) else w.data_ptr(), y.data_ptr(),
                         bias.data_ptr() if bias is not None else 0, rowadd.data_ptr() if rowadd is not None else 0,
                         residual.data_ptr() if residual is not None else 0, preact.data_ptr() if preact is not None else 0,
-                        dact_u.data_ptr() if dact_u is not None else 0)
+                        dact_u.data_ptr() if dact_u is not None else 0, 0, 0)
+    # small grids (sampling, small batches): offer a split-K workspace.  Only launches with few output elements are asked
+    # about (one plan evaluation on the host); a batch-256 train step never is.
+    if B * Ho * Wo * Cout <= _SPLITK_MAX_OUT and _SPLITK:
+        need = lib.psg_conv_fwd_workspace_bytes(cp)
+        if need > 0:
+            ws = _lib.workspace(need, x.device)
+            struct.pack_into("<Qq", cb, _CONV_FMT.size - 16, ws.data_ptr(), ws.numel())
+            SplitKStats.launches += 1
     check(lib.psg_conv_fwd(cp, stream_ptr()), "psg_conv_fwd")
 
 

@@ -694,3 +694,50 @@ def test_wgrad_wide_tiles(psg, B, H, Cin, Cout, ks, layout):
     assert maxrel(wd.grad.cpu(), 2 * w.grad) < 1e-4, "wgrad accumulate"
     assert maxrel(bd.grad.cpu(), 2 * b.grad) < 1e-4, "bias accumulate"
     arena.release()
+
+
+# (B, H, Cin, Cout, ks, stride): small output grids with a long K axis - the launches psg_conv_fwd splits along K when it
+# is offered a workspace (sampling at 64 samples on the 7x7 / 4x4 levels, training batches of 2-4)
+SPLITK_CASES = [(2, 7, 1280, 1280, 3, 1), (4, 4, 2560, 1280, 3, 1), (3, 7, 2560, 640, 1, 1), (1, 14, 640, 640, 3, 1), (6, 4, 1280, 2560, 1, 1),
+                (2, 14, 320, 640, 3, 2)]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("B,H,Cin,Cout,ks,stride", SPLITK_CASES)
+def test_conv_splitk_matches_unsplit(psg, dtype, B, H, Cin, Cout, ks, stride):
+    """Split-K forward and data gradient (fp32 partial tiles + finishing kernel with the run-time epilogue) against the
+    unsplit launch of the same operands and against the CPU convolution: bias, per-sample add, residual, SiLU, gate."""
+    from pokemon_sprite_generator_amd import ops
+    pad = 1 if ks == 3 else 0
+    name = f"sk{B}.{H}.{Cin}.{Cout}.{ks}.{stride}"
+    x = _q(h((B, Cin, H, H), name + "x", 1.2), dtype).requires_grad_(True)
+    w = _q(h((Cout, Cin, ks, ks), name + "w", math.sqrt(3.0 / (Cin * ks * ks))), dtype)
+    b = h((Cout,), name + "b", 0.2)
+    ref = F.conv2d(x, w, b, stride=stride, padding=pad)
+    Ho = ref.shape[-1]
+    ra = _q(h((B, Cout), name + "ra", 0.5), dtype)
+    res = _q(h((B, Cout, Ho, Ho), name + "res", 1.0), dtype)
+    ref = res + 0.7 * F.silu(ref + ra[:, :, None, None])
+    gy = _q(h(tuple(ref.shape), name + "gy", 1.0), dtype)
+    ref.backward(gy)
+    outs = {}
+    saved = ops._SPLITK
+    try:
+        for split in (False, True):
+            ops._SPLITK = split
+            n0 = ops.SplitKStats.launches
+            xd = to_cl(x.detach(), dtype).to(DEV).requires_grad_(True)
+            y = ops.conv2d(xd, w.to(DEV), b.to(DEV), stride=stride, rowadd=ra.to(dtype).to(DEV), residual=to_cl(res, dtype).to(DEV),
+                           act=ops.ACT_SILU, alpha=0.7)
+            y.backward(to_cl(gy, dtype).to(DEV))
+            outs[split] = (from_cl(y.detach().cpu()), from_cl(xd.grad.cpu()), ops.SplitKStats.launches - n0)
+    finally:
+        ops._SPLITK = saved
+    assert outs[False][2] == 0
+    assert outs[True][2] >= 1, "the launch was not offered / did not want a split-K workspace"
+    tol = TOL[dtype]
+    for i, what in ((0, "forward"), (1, "dgrad")):
+        refv = ref.detach() if i == 0 else x.grad
+        assert maxrel(outs[True][i], refv) < tol, what + " (split) vs CPU"
+        # same products, another fp32 summation order (and one rounding to the output dtype)
+        assert maxrel(outs[True][i], outs[False][i]) < (2e-5 if dtype == torch.float32 else 1.6e-2), what + " split vs unsplit"

@@ -568,7 +568,10 @@ def test_gradient_batch_linearity_b64(dtype):
     mean = (acc / (B // 2)).float()
     assert abs(lsum / (B // 2) - loss64) < 1e-5 * max(1.0, abs(loss64))
     # per parameter: rel-L2 of the batch-64 gradient against the mean of the batch-2 gradients
-    bar = 1e-4 if dtype == torch.float32 else 2e-3
+    # fp32: summation order only.  bf16: the bars of test_train_step_golden_bf16 (sampled slices rel-L2 < 4e-2) - the batch-2
+    # passes take split-K data gradients (fp32 partial tiles, one rounding) where batch 64 takes the unsplit kernel, so
+    # individual bf16 roundings differ and the difference accumulates down the backward chain (measured worst: 1.7e-2, init_conv)
+    bar = 1e-4 if dtype == torch.float32 else 4e-2
     worst, worst_name, zero = 0.0, None, []
     for (name, p), off in zip([(n, q) for n, q in unet.named_parameters() if q.requires_grad], st.arena.offsets):
         a, b = big[off:off + p.numel()].double(), mean[off:off + p.numel()].double()
