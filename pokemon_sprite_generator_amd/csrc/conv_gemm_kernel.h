@@ -212,7 +212,10 @@ __device__ __forceinline__ int conv_out_m(const ConvP& p, int mt) {
 //         gather is a stride-1 gather with 1, 2 or 4 taps (table in ConvP) instead of 9 taps of which 3/4 miss
 // 256 threads = 4 waves (2 along m x 2 along n), two LDS tile buffers: the tile of step kt+1 is requested at the top
 // of step kt (plain __syncthreads at the end of the step).
-template <typename T, int BM, int BN, int MODE>
+// SPLITK: the split-K form (small output grids) is its OWN instantiation - it has no epilogue at all, and the epilogue-heavy
+// plain kernels keep their register allocation (as a run-time branch inside them it cost 274 more spilled registers and
+// 17 % of the forward / data-gradient families).
+template <typename T, int BM, int BN, int MODE, bool SPLITK = false>
 __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
 #if defined(__HIP_DEVICE_COMPILE__)      // the LDS-DMA builtin exists only in the device pass
     constexpr int NT = 256;
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
         const int nb = gridDim.x, bid = blockIdx.x;
         const int q = nb >> 3, r = nb & 7, xcd = bid & 7;
         int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-        if (p.splits > 1) { const int tiles = p.mtiles * p.ntiles; split = lid / tiles; lid -= split * tiles; }   // split slowest
+        if constexpr (SPLITK) { const int tiles = p.mtiles * p.ntiles; split = lid / tiles; lid -= split * tiles; }   // split slowest
         constexpr int GM = 8;
         const int per_group = GM * p.ntiles;
         const int g = lid / per_group, rem = lid - g * per_group;
@@ -294,12 +297,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
     }
 
     // this workgroup's K steps [kt0, kt1) (the whole K axis unless split-K)
-    const int kt0 = split * p.kt_per_split;
-    const int kt1 = p.splits > 1 ? min(p.KT, kt0 + p.kt_per_split) : p.KT;
+    const int kt0 = SPLITK ? split * p.kt_per_split : 0;
+    const int kt1 = SPLITK ? min(p.KT, kt0 + p.kt_per_split) : p.KT;
     // uniform tap state of the NEXT K step to load (fast modes): chunk offset inside the tap, kh, kw - at step kt0 of the
     // taps-innermost walk (MODE 3: t_kh indexes the class's tap table)
     int t_c0 = 0, t_kh = 0, t_kw = 0;
-    if (p.splits > 1 && kt0 > 0) {
+    if (SPLITK && kt0 > 0) {
         if (MODE == 3) { t_c0 = (kt0 / p.ntap) * 8; t_kh = kt0 % p.ntap; }
         else if (MODE != 2) { const int tp = kt0 % p.taps; t_c0 = (kt0 / p.taps) * 8; t_kh = tp / p.ks; t_kw = tp - t_kh * p.ks; }
     }
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
             const int mt_ = m0 + wm * WM + j * 16 + l16;
             rows[j] = -1; smp[j] = 0;
             if (mt_ < p.M) conv_out_row<MODE>(p, mt_, rows[j], smp[j]);
-            if (resg && !p.epi_lds) {
+            if (!SPLITK && resg && !p.epi_lds) {
 #pragma unroll
                 for (int i = 0; i < NA; ++i) {
                     const int n = n0 + wn * WN + i * 16 + 4 * kq;
@@ -484,7 +487,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
     // fetch goes out NOW and flies under the step's MFMAs.  vmcnt retires in order: issued any earlier these HBM-latency
     // loads sit in front of a tile DMA and the wait for that tile waits for them too (behind the first tile, as before,
     // they stretched every workgroup's prologue: a residual cost a K<=1280 Linear 35-50 % more than its bandwidth).
-    if (p.splits > 1) {
+    if constexpr (SPLITK) {
         // split-K: this workgroup's share of the reduction goes out as an fp32 partial tile; the epilogue runs in the
         // finishing kernel (fixed summation order over the splits: deterministic)
         compute((kt1 - 1 - kt0) & 1);
@@ -516,7 +519,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
             }
         }
         return;
-    }
+    } else {
     if constexpr (FT16) {
         // (the bias too: even as L2 hits its loads, issued behind the first tile, held every workgroup's first wait for
         //  0.5-1 us - a bias cost a K = 640 Linear 12-18 %)
@@ -787,6 +790,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
             }
         }
     }
+    }   // !SPLITK
 #endif
 }
 
@@ -826,7 +830,12 @@ int launch_conv(const ConvP& p, hipStream_t stream) {
     const ConvP fin = q;                               // (the finishing kernel runs the epilogue: it keeps the operands)
     if (q.splits > 1) { q.bias = nullptr; q.rowadd = nullptr; q.residual = nullptr; q.preact = nullptr; q.dact_u = nullptr; }
     const int mode = p.ntap > 0 ? 3 : (!p.fast ? 2 : (!p.transposed ? 0 : (p.stride == 1 ? 1 : 2)));
-    if (mode == 3) {
+    if (q.splits > 1) {
+        if (mode == 0) hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 0, true>), dim3(grid), dim3(256), lds, stream, q);
+        else if (mode == 1) hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 1, true>), dim3(grid), dim3(256), lds, stream, q);
+        else if (mode == 2) hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 2, true>), dim3(grid), dim3(256), lds, stream, q);
+        else return set_error(PSG_ERR_ARG, "conv_gemm: parity-class launches are never split");
+    } else if (mode == 3) {
         // (the 160-wide tiles are not built for the parity-class mode: its tap tables push the kernel past the scalar
         //  register file - one layer, the first downsample's data gradient, runs 128x128 instead)
         if constexpr (BN != 160) hipLaunchKernelGGL((conv_gemm_kernel<T, BM, BN, 3>), dim3(grid), dim3(256), lds, stream, q);
@@ -851,6 +860,9 @@ int set_conv_attrs() {
     PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 0>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     if constexpr (BN != 160)
         PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_gemm_kernel<T, BM, BN, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     return PSG_OK;
