@@ -350,7 +350,15 @@ __global__ __launch_bounds__(256, (ND <= 5 ? 2 : 1)) void attn_dkv_mfma(const At
     const int nqt = Lp >> 5;
     char* Kw = KVw + wave * (2 * 32 * STR);
     char* Vw = Kw + 32 * STR;
-    for (int kt = wave; kt * 32 < Sp; kt += (int)(blockDim.x >> 6)) {
+    // Waves = KW key tiles x QW query groups.  With more waves than key tiles (cross-attention: S = 32 is ONE key tile, and the
+    // whole workgroup used to be one wave walking all query tiles) the query tiles are dealt to QW waves per key tile; their
+    // partial dK / dV meet in LDS - the Q / dO images are dead by then - and query group 0 adds them in fixed order.
+    // QW > 1 only when every wave has exactly one key tile (KW == number of key tiles): the barriers below are uniform.
+    const int W = (int)(blockDim.x >> 6), nkt_all = Sp >> 5;
+    const int KW = min(nkt_all, W), QW = max(1, W / KW);
+    const int kw = wave % KW, qw = wave / KW;
+    const bool active = qw < QW;
+    for (int kt = kw; kt * 32 < Sp; kt += KW) {
         const int key = kt * 32 + fr;
         const bool kok = key < p.S;
         bf16x8 kreg[KV_REG ? ND : 1], vreg[KV_REG ? ND : 1];
@@ -382,7 +390,7 @@ __global__ __launch_bounds__(256, (ND <= 5 ? 2 : 1)) void attn_dkv_mfma(const At
         for (int t = 0; t < TH; ++t)
 #pragma unroll
             for (int e = 0; e < 16; ++e) { dk[t][e] = 0.f; dv[t][e] = 0.f; }
-        for (int qt = 0; qt < nqt; ++qt) {
+        for (int qt = active ? qw : nqt; qt < nqt; qt += QW) {
             f32x16 st, dp;
 #pragma unroll
             for (int e = 0; e < 16; ++e) { st[e] = 0.f; dp[e] = 0.f; }
@@ -434,7 +442,28 @@ __global__ __launch_bounds__(256, (ND <= 5 ? 2 : 1)) void attn_dkv_mfma(const At
                 dk[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(q1, sf1, dk[t], 0, 0, 0);
             }
         }
-        if (kok) {
+        if (QW > 1) {                            // (workgroup-uniform)
+            __syncthreads();                     // every wave is done with the Q / dO images
+            float* red = reinterpret_cast<float*>(smem);
+            if (active && qw > 0) {
+                float* dst = red + (int64_t)((qw - 1) * KW + kw) * (TH * 2 * 16 * 64) + lane;
+#pragma unroll
+                for (int t = 0; t < TH; ++t)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) { dst[((t * 2) * 16 + e) * 64] = dk[t][e]; dst[((t * 2 + 1) * 16 + e) * 64] = dv[t][e]; }
+            }
+            __syncthreads();
+            if (qw == 0) {
+                for (int q2 = 1; q2 < QW; ++q2) {
+                    const float* src = red + (int64_t)((q2 - 1) * KW + kw) * (TH * 2 * 16 * 64) + lane;
+#pragma unroll
+                    for (int t = 0; t < TH; ++t)
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) { dk[t][e] += src[((t * 2) * 16 + e) * 64]; dv[t][e] += src[((t * 2 + 1) * 16 + e) * 64]; }
+                }
+            }
+        }
+        if (kok && qw == 0) {
 #pragma unroll
             for (int t = 0; t < TH; ++t)
 #pragma unroll
@@ -467,8 +496,21 @@ static inline size_t dkv_lds_w(int L, int d, int waves) {
 // waves of the dK/dV kernel: one per 32-key tile, fewer when their private K/V tiles would not fit LDS next to the
 // Q / dO images (head_dim 320 = the reference CLI's 4 heads at 1280 channels: 7x7 self-attention runs 1 wave)
 static inline int dkv_waves(int L, int S, int d) {
-    int w = attn_waves(S);
-    while (w > 1 && dkv_lds_w(L, d, w) > MFMA_LDS_CAP) --w;
+    const int nkt = (S + 31) / 32, nqt = (L + 31) / 32;
+    int kw = attn_waves(S);
+    // query groups per key tile (round 3): only when the key tiles do not fill the workgroup (S = 32: one tile; 49: two), the
+    // partial sums fit the dead Q / dO images, and K / V ride in registers (head_dim <= 80: at 160 every extra wave stages a
+    // private K / V tile, and the 7x7 cross-attention backward went from 125 to 154 us with two query groups)
+    int qw = 1;
+    if (d <= 80 && nkt <= 2 && kw == nkt) {
+        qw = 4 / kw;
+        if (qw > nqt) qw = nqt;
+        if (qw < 1) qw = 1;
+        const size_t th = (size_t)((d / 16 + 1) / 2);
+        while (qw > 1 && ((size_t)(qw - 1) * kw * th * 8192 > dkv_lds_w(L, d, kw * qw) || dkv_lds_w(L, d, kw * qw) > MFMA_LDS_CAP)) --qw;
+    }
+    int w = kw * qw;
+    if (qw == 1) while (w > 1 && dkv_lds_w(L, d, w) > MFMA_LDS_CAP) --w;
     return w;
 }
 static inline size_t dkv_lds_m(int L, int S, int d) { return dkv_lds_w(L, d, dkv_waves(L, S, d)); }
