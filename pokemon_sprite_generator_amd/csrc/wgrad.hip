@@ -17,6 +17,7 @@
 // memory order (OHWI: no permute; one split: tiles written directly); the bias
 // gradient rides along as one extra MFMA per dY fragment against a ones operand.
 #include "psg_common.h"
+#include <type_traits>
 
 namespace psg {
 
@@ -595,6 +596,298 @@ __global__ __launch_bounds__(256, 2) void wgrad_wide_kernel(const WgP p) {
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Pipelined 320 x 192 tile (round 3): ONE wave per SIMD with the whole register file.  4 waves = 2 (co) x 2 (q), each
+// 160 co x 96 q = 10 x 6 MFMA tiles (240 accumulator registers: they fit the 256 AGPRs; 320 x 256 = 320 accumulators did not,
+// hipcc spilled 417 registers).  K step = 32 pixels, a ring of four 32 KB stages: the tile of step k+3 is requested during
+// step k, the tiles of steps k and k+1 have landed at the barrier that opens step k.  There is no second workgroup to hide a
+// wave's LDS latency behind, so the wave software-pipelines itself: during the ten MFMAs that use X fragment j it fetches X
+// fragment j+1, a share of the NEXT step's dY fragments and a share of the ring's DMA pieces; fragment registers are
+// double-buffered (dY: 2 x 10, X: 2 x 1).  32 KB staged per 3.9 MFLOP (1.9x fewer bytes per FLOP than 128 x 128 x 64), 0.53
+// transposing reads per MFMA instead of 1.0.  320 divides every Cout of the network, 192 every 3x3 layer's 9 Cin.
+// Both images have rows of 1.5 / 2.5 bank periods (384 / 640 bytes: odd pixels start 128 bytes into the period): chunk bits
+// 1-2 XOR ((px & 3) >> 1 | ((px >> 3) & 1) << 1) spread the 8 rows of a half-wave's transposed read over the eight 32-byte
+// bank windows.  The X image keeps wgrad_wide_kernel's row order (b4, b2, b3, b1 b0) so that a lane's (tap, ci) decode is
+// the same in all four staging passes; 24 chunks x 8 rows = 192 lanes per pass: waves 0-2 stage X, all four stage dY.
+// bf16, stride-1 geometries.
+// Bias gradient (BIAS): every workgroup multiplies ONE dY fragment per K step with a ones operand - fragment qt % 10 of its
+// wave's half, so the first ten q tiles of a row tile cover all ten fragments between them (the launcher takes this kernel
+// only for >= 10 q tiles).  Spread like this it costs every workgroup one MFMA and two reads in sixty and no branch; as ten
+// MFMAs in the workgroups of q tile 0 it would stretch exactly those workgroups by 17 % - and a launch is one round of them.
+template <int GEOM, bool BIAS>
+__global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgP p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int CH = 8, BKP = 32, BR = 320, BQ = 192, ESZ = 2;
+    constexpr int AROWB = BR * ESZ, BROWB = BQ * ESZ;              // 640, 384
+    constexpr int ACH = BR / CH, BCH = BQ / CH;                    // 40 / 24 chunks per row
+    constexpr int NPA = 5, NPB = 4, APASS = 4096, BPASS = 192 * 16;   // dY: 1280 chunks = 5 x 256 lanes; X: 768 = 4 x 192 lanes
+    constexpr int AREG = NPA * APASS, BTILE = BKP * BROWB;         // 20 KB, 12 KB
+    constexpr int STAGE = AREG + BTILE;                            // 32 KB
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave & 1, wc = wave >> 1;
+    int lid;
+    {
+        const int nb = gridDim.x, b0 = blockIdx.x;
+        const int q = nb >> 3, r = nb & 7, xcd = b0 & 7;
+        lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b0 >> 3);
+    }
+    const int tiles = p.rtiles * p.qtiles;
+    const int split = lid / tiles;
+    const int tix = lid - split * tiles;
+    const int rt = tix % p.rtiles, qt = tix / p.rtiles;
+    const int co0 = rt * BR, q0 = qt * BQ;
+    const int step0 = split * p.steps_per_split;
+    const int total_steps = (p.M + BKP - 1) / BKP;
+    int nsteps = total_steps - step0;
+    if (nsteps > p.steps_per_split) nsteps = p.steps_per_split;
+
+    constexpr uint32_t OOB = 0x80000000u;
+    const u32x4 yrs = make_rsrc(p.dy, p.dy_bytes);
+    const int ldxB = (int)p.ldx * ESZ, lddyB = (int)p.lddy * ESZ;
+    // dY staging: element e = 256 j + tid of pass j sits at (row e / 40, physical chunk e % 40) and fetches the logical chunk
+    // physical ^ key(row); rows >= M lie beyond the descriptor's extent and read as zeros (Cout % 320 == 0: no column tail)
+    uint32_t a_voff[NPA];
+#pragma unroll
+    for (int j = 0; j < NPA; ++j) {
+        const int e = j * 256 + tid, row = e / ACH, pc = e - row * ACH;
+        const int lc = pc ^ ((((row & 3) >> 1) | (((row >> 3) & 1) << 1)) << 1);
+        a_voff[j] = (uint32_t)(((step0 * BKP + row) * (int)p.lddy + co0 + lc * CH) * ESZ);
+    }
+    // X staging (lanes 0..191): pass j = pixels pxB + 16 (j >> 1) + 4 (j & 1), LDS rows 8 j + r8
+    const bool xlane = tid < 192;                                   // (waves 0-2: wave-uniform)
+    const int r8 = xlane ? tid / BCH : 0, pcB = xlane ? tid - r8 * BCH : 0;
+    const int pxB = ((r8 >> 2) << 3) | (r8 & 3);
+    const int lcB = pcB ^ ((((pxB & 3) >> 1) | (((pxB >> 3) & 1) << 1)) << 1);
+    const int b_q = q0 + lcB * CH;
+    const bool b_ok = xlane && b_q < p.Q;
+    const int b_tap = b_ok ? b_q / p.Cin : 0;
+    const int b_ci = b_q - b_tap * p.Cin;
+    const int b_kh = b_tap / p.ks, b_kw = b_tap - b_kh * p.ks;
+    const int HoWo = p.Ho * p.Wo;
+    const int ho_lo = max(0, p.pad - b_kh), wo_lo = max(0, p.pad - b_kw);
+    const int ho_hi = min(p.Ho - 1, p.Hi - 1 + p.pad - b_kh), wo_hi = min(p.Wo - 1, p.Wi - 1 + p.pad - b_kw);
+    const bool b_in = b_ok && ho_hi >= ho_lo && wo_hi >= wo_lo;
+    const unsigned w_rng = (unsigned)(wo_hi - wo_lo);
+    const int rm_lo = ho_lo * p.Wo;
+    const unsigned rm_rng = (unsigned)((ho_hi + 1) * p.Wo - 1 - rm_lo);
+    typedef __attribute__((address_space(3))) char* lds_ptr_t;
+    const uint32_t lds_wave = (uint32_t)(size_t)(lds_ptr_t)smem + (uint32_t)__builtin_amdgcn_readfirstlane(wave) * 1024u;
+    int g_mB = step0 * BKP + pxB;
+    const int g_shift = (p.pad * p.Wi + p.pad) * ldxB;
+    const u32x4 xrs_g = make_rsrc(reinterpret_cast<const char*>(p.x) - g_shift, p.x_bytes + (uint32_t)g_shift);
+    int g_b = g_mB * ldxB + (b_kh * p.Wi + b_kw) * ldxB + b_ci * ESZ;
+    const int st_rm = BKP % HoWo, st_wo = BKP % p.Wo;
+    int g_rm[NPB], g_wo[NPB];
+#pragma unroll
+    for (int j = 0; j < NPB; ++j) {
+        g_rm[j] = (g_mB + 16 * (j >> 1) + 4 * (j & 1)) % HoWo;
+        g_wo[j] = g_rm[j] % p.Wo;
+    }
+    const uint32_t a_step = (uint32_t)(BKP * lddyB);
+    const int b_step = BKP * ldxB;
+    const bool xwave = __builtin_amdgcn_readfirstlane(wave) < 3;   // this wave's lanes stage X pieces; wave 3's X pieces are
+    // out-of-range dummies into a scratch KB behind the ring, so that EVERY wave issues 9 pieces per tile: one vmcnt count
+    // for all waves and no branch in the steady-state loop
+    const uint32_t lds_dummy = (uint32_t)(size_t)(lds_ptr_t)smem + 4u * STAGE;
+    // the DMA pieces of the tile being requested: 5 dY passes, 4 X passes.  An X piece is two halves for the instruction
+    // interleave below: x_track computes the piece's offset (and advances the border trackers), x_issue sends it
+    auto a_piece = [&](int pc, uint32_t stage_base) {
+        lds_dma16(yrs, stage_base + pc * APASS, a_voff[pc]);
+        a_voff[pc] += a_step;
+    };
+    auto x_track = [&](int j) -> uint32_t {
+        const int po = 16 * (j >> 1) + 4 * (j & 1);
+        bool ok = b_in && g_mB < p.M - po;
+        if constexpr (GEOM == 1) {
+            ok = ok && (unsigned)(g_rm[j] - rm_lo) <= rm_rng && (unsigned)(g_wo[j] - wo_lo) <= w_rng;
+            int rm = g_rm[j] + st_rm; rm -= rm >= HoWo ? HoWo : 0; g_rm[j] = rm;
+            int wo = g_wo[j] + st_wo; wo -= wo >= p.Wo ? p.Wo : 0; g_wo[j] = wo;
+        }
+        return ok ? (uint32_t)g_b : OOB;
+    };
+    auto x_issue = [&](int j, uint32_t boff, uint32_t stage_base) {
+        const int po = 16 * (j >> 1) + 4 * (j & 1);
+        const uint32_t dst = xwave ? stage_base + AREG + j * BPASS : lds_dummy;      // (scalar select)
+        lds_dma16s(xrs_g, dst, boff, (uint32_t)(po * ldxB));
+        if (j == NPB - 1) { g_mB += BKP; g_b += b_step; }                             // (the last X pass advances the pixel odometer)
+    };
+    auto dma_piece = [&](int pc, uint32_t stage_base) {
+        if (pc < NPA) a_piece(pc, stage_base);
+        else x_issue(pc - NPA, x_track(pc - NPA), stage_base);
+    };
+    // all but the newest `tiles_in_flight` tiles' pieces of this wave have landed (9 pieces per tile and wave)
+    auto wait_tiles = [&](int tiles_in_flight) {
+        if (tiles_in_flight == 0) wait_vmcnt<0>();
+        else if (tiles_in_flight == 1) wait_vmcnt<9>();
+        else wait_vmcnt<18>();
+    };
+
+    typedef float AccT __attribute__((ext_vector_type(4)));
+    AccT acc[10][6];
+#pragma unroll
+    for (int i = 0; i < 10; ++i)
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][e] = 0.f;
+
+    const int g = lane >> 4, i16 = lane & 15, q4 = i16 >> 2, p4 = i16 & 3;
+    const int key = ((q4 >> 1) | ((g & 1) << 1)) << 1;             // both images (pixels 8g + q4 and 8g + 4 + q4)
+    const int rowa = (8 * g + q4) * AROWB + 8 * (p4 & 1);
+    const int chA = wr * 20 + (p4 >> 1);
+    // bias gradient: this workgroup's fragment of the dY tile (wave-uniform index), its accumulator and the ones operand
+    const int ib = qt % 10;
+    const int biasoff = rowa + (((chA + 2 * ib) ^ key) << 4);
+    AccT accb = {0.f, 0.f, 0.f, 0.f};
+    bf16x8 ones;
+    {
+        const bf16_t one = (bf16_t)1.0f;
+        const bf16x8 o = {one, one, one, one, one, one, one, one};
+        ones = o;
+    }
+    const int rowb = AREG + (((g >> 1) << 4) | ((g & 1) << 2) | q4) * BROWB + 8 * (p4 & 1);
+    const int chB = wc * 12 + (p4 >> 1);
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    auto rd_a = [&](const char* sb, int i) {
+        const char* a = sb + rowa + (((chA + 2 * i) ^ key) << 4);
+        s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a));
+        s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a + 4 * AROWB));
+        s16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        return *reinterpret_cast<bf16x8*>(&av);
+    };
+    auto rd_b = [&](const char* sb, int j) {
+        const char* b = sb + rowb + (((chB + 2 * j) ^ key) << 4);
+        s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b));
+        s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(b + 8 * BROWB));
+        s16x8 bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        return *reinterpret_cast<bf16x8*>(&bv);
+    };
+
+    // ---- prologue: tiles 0, 1, 2 requested; tiles 0 and 1 landed; tile 0's dY fragments and X fragment 0 in registers
+    const uint32_t lds0 = lds_wave;
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+        if (t < nsteps) {
+#pragma unroll
+            for (int pc = 0; pc < 9; ++pc) dma_piece(pc, lds0 + (uint32_t)t * STAGE);
+        }
+    wait_tiles(nsteps > 2 ? 1 : 0);                    // (step 0 prefetches from tile 1)
+    __syncthreads();
+    bf16x8 afA[10], afB[10], bf0, bf1;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) afA[i] = rd_a(smem, i);
+    bf0 = rd_b(smem, 0);
+
+    // one K step: the MFMAs of tile k (dY fragments `cur`, staged in buffer `b`), the prefetch of tile k+1's dY fragments into
+    // `nxt` from buffer `nb`, the request of tile k+3 into buffer `ib`.  FULL: both are known to exist (steady state: no branch)
+    auto kstep = [&](auto full_c, bf16x8 (&cur)[10], bf16x8 (&nxt)[10], int b, int nb, int ib, bool have_next_rt, bool issue_rt) {
+        constexpr bool FULL = decltype(full_c)::value;
+        const bool have_next = FULL || have_next_rt, issue = FULL || issue_rt;
+        const char* sb = smem + b * STAGE;
+        const char* sn = smem + nb * STAGE;
+        const uint32_t ibase = lds0 + (uint32_t)ib * STAGE;
+        // One wave per SIMD: nothing else hides what this wave does between two MFMAs, and an MFMA occupies the pipe for 16
+        // cycles = four issue slots.  So the non-MFMA work of a group (6 fragment reads, 1-2 DMA pieces, their address VALU) is
+        // dealt out by hand, a slice behind each of the group's ten MFMAs, and pinned there with sched_barrier (as one block in
+        // front of the ten MFMAs - the first form of this kernel - the pipe sat idle for ~250 of every ~410 cycles).
+        auto trA = [&](const char* sb_, int i, int half) {
+            return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sb_ + rowa + (((chA + 2 * i) ^ key) << 4) + half * 4 * AROWB));
+        };
+        auto trB = [&](const char* sb_, int j_, int half) {
+            return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sb_ + rowb + (((chB + 2 * j_) ^ key) << 4) + half * 8 * BROWB));
+        };
+        auto cat = [&](s16x4 a, s16x4 c) { s16x8 v = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]}; return *reinterpret_cast<bf16x8*>(&v); };
+        s16x4 w0 = {0, 0, 0, 0}, w1 = {0, 0, 0, 0};
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            bf16x8& bc = (j & 1) ? bf1 : bf0;
+            bf16x8& bn = (j & 1) ? bf0 : bf1;
+            const bool rdb = j < 5 || have_next;                       // the next X fragment: this tile's j+1, or the next tile's 0
+            const char* sbn = j < 5 ? sb : sn;
+            const int jn = j < 5 ? j + 1 : 0;
+            const bool rda = have_next && j < 5;                       // two of the next tile's dY fragments
+            const int xj = j < 3 ? j : (j == 5 ? 3 : -1);             // X pass requested in this group (pass 3 last: it advances the odometer)
+            s16x4 t0, t1, u0, u1, v0, v1;
+            uint32_t xoff = 0;
+#pragma unroll
+            for (int i = 0; i < 10; ++i) {
+                asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[i][j]) : "v"(cur[i]), "v"(bc));
+                if (i == 0 && rdb) t0 = trB(sbn, jn, 0);
+                if (i == 1 && rdb) t1 = trB(sbn, jn, 1);
+                if (i == 2 && rda) u0 = trA(sn, 2 * j, 0);
+                if (i == 3 && rda) u1 = trA(sn, 2 * j, 1);
+                if (i == 4 && rda) v0 = trA(sn, 2 * j + 1, 0);
+                if (i == 5 && rda) v1 = trA(sn, 2 * j + 1, 1);
+                if (i == 6 && issue && j < 5) a_piece(j, ibase);
+                if (i == 7 && issue && xj >= 0) xoff = x_track(xj);
+                if (i == 8 && issue && xj >= 0) x_issue(xj, xoff, ibase);
+                if constexpr (BIAS) {                  // (groups 3 / 4 have the lightest slices)
+                    if (j == 3 && i == 8) w0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sb + biasoff));
+                    if (j == 3 && i == 9) w1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sb + biasoff + 4 * AROWB));
+                    if (j == 4 && i == 9) { const bf16x8 wf = cat(w0, w1); asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(accb) : "v"(wf), "v"(ones)); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (rdb) bn = cat(t0, t1);
+            if (rda) { nxt[2 * j] = cat(u0, u1); nxt[2 * j + 1] = cat(v0, v1); }
+        }
+    };
+    // (a step has 6 X fragments, so fragment 0 of every tile sits in bf0)
+    int b = 0, st = 0;
+    for (; st + 4 < nsteps; st += 2) {                 // steady state: tiles st+1 .. st+4 all exist
+        kstep(std::true_type{}, afA, afB, b, (b + 1) & 3, (b + 3) & 3, true, true);
+        wait_vmcnt<9>();                               // tile st+2 landed; tile st+3 (just requested) may fly
+        __syncthreads();
+        kstep(std::true_type{}, afB, afA, (b + 1) & 3, (b + 2) & 3, b, true, true);
+        wait_vmcnt<9>();
+        __syncthreads();
+        b = (b + 2) & 3;
+    }
+    for (; st < nsteps; st += 2) {                     // the last (up to four) steps
+        {
+            const bool have_next = st + 1 < nsteps, issue = st + 3 < nsteps;
+            kstep(std::false_type{}, afA, afB, b, (b + 1) & 3, (b + 3) & 3, have_next, issue);
+            if (st + 2 < nsteps) wait_tiles(issue ? 1 : 0);
+            __syncthreads();
+            b = (b + 1) & 3;
+        }
+        if (st + 1 < nsteps) {
+            const bool have_next = st + 2 < nsteps, issue = st + 4 < nsteps;
+            kstep(std::false_type{}, afB, afA, b, (b + 1) & 3, (b + 3) & 3, have_next, issue);
+            if (st + 3 < nsteps) wait_tiles(issue ? 1 : 0);
+            __syncthreads();
+            b = (b + 1) & 3;
+        }
+    }
+
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");    // the asm MFMAs are invisible to the hazard recogniser: drain before the accumulators are read
+    float* wsb = p.ws + (int64_t)split * p.Cout * p.Q;
+    const int l16 = lane & 15, kq = lane >> 4;
+    if constexpr (BIAS) {
+        if (wc == 0 && qt < 10 && l16 == 0) {          // column 0 of the ones-product holds the sums of fragment ib
+            float* bw = p.bws + (int64_t)split * p.Cout;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bw[co0 + wr * 160 + ib * 16 + 4 * kq + r] = accb[r] * p.scale;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int q = q0 + wc * 96 + j * 16 + l16;
+        if (q >= p.Q) continue;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wr * 160 + i * 16 + 4 * kq + r;
+                wsb[(int64_t)co * p.Q + q] = acc[i][j][r] * p.scale;
+            }
+        }
+    }
+#endif
+}
+
 // dw[co][ci][tap] (+)= sum_s ws[s][co][tap*Cin + ci]; one block per (co, 256-ci chunk), LDS transpose
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, int Cout, int Cin, int taps,
                                     int splits, int accumulate) {
@@ -670,9 +963,23 @@ static void wgrad_plan(const psg_wgrad_desc* d, WgP& p) {
         const int64_t tiles128 = (int64_t)((d->Cout + 127) / 128) * ((p.Q + 127) / 128);
         if (!off && d->dtype == PSG_BF16 && same && p.BR == 128 && q256 * 100 <= (int64_t)p.Q * 105 && tiles128 >= 200) { p.wide = 1; BKP = 32; }
     }
-    const int kSlots = 512;
+    int kSlots = 512;
+    {
+        // pipelined 320 x 256 tiles (one 256-thread workgroup per CU, wgrad_pipe_kernel): 320 divides Cout, the 256-column grid
+        // wastes < 4 %, enough tiles, >= 10 q tiles (they share out the bias gradient's fragments) (PSG_WGRAD_PIPE=0: off)
+        static int off = -1;
+        if (off < 0) { const char* e = getenv("PSG_WGRAD_PIPE"); off = (e && atoi(e) == 0) ? 1 : 0; }
+        static int mint = -1;
+        if (mint < 0) { const char* e = getenv("PSG_WGRAD_PIPE_MIN_TILES"); mint = e ? atoi(e) : 15; }
+        const bool same = d->stride == 1 && d->Hi == d->Ho && d->Wi == d->Wo;
+        const int64_t q192 = ((int64_t)p.Q + 191) / 192 * 192;
+        const int64_t tiles320 = (int64_t)(d->Cout / 320) * (q192 / 192);
+        const int64_t ext = ((int64_t)p.M + 64) * d->lddy * 2;
+        if (!off && d->dtype == PSG_BF16 && same && d->Cout % 320 == 0 && q192 * 100 <= (int64_t)p.Q * 104 && tiles320 >= mint && q192 / 192 >= 10 &&
+            ext < 0x7FFFFFF0ll) { p.wide = 3; p.BR = 320; BKP = 32; kSlots = 256; }
+    }
     p.rtiles = (d->Cout + p.BR - 1) / p.BR;
-    p.qtiles = p.wide ? (p.Q + 255) / 256 : (p.Q + 127) / 128;
+    p.qtiles = p.wide == 3 ? (p.Q + 191) / 192 : (p.wide ? (p.Q + 255) / 256 : (p.Q + 127) / 128);
     const int total_steps = (p.M + BKP - 1) / BKP;
     const int tiles = p.rtiles * p.qtiles;
     // Split-K choice by a makespan model: 2 workgroups (64 KB LDS each) per CU x 256 CUs = 512 slots; a launch runs
@@ -722,6 +1029,10 @@ int psg_wgrad_init_attrs(void) {
 #undef PSG_WG_ATTR
     PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<bf16_t, 1, 160>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (320 + 256)));
     PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_kernel<bf16_t, 2, 160>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 64 * (320 + 256)));
+    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_pipe_kernel<1, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 1024));
+    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_pipe_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 1024));
+    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_pipe_kernel<1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 1024));
+    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_pipe_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 32768 + 1024));
     PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wide_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (8192 + 16384)));
     PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wide_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (8192 + 16384)));
     return PSG_OK;
@@ -795,7 +1106,16 @@ int psg_conv_wgrad(const psg_wgrad_desc* d, psg_stream_t stream) {
 #define PSG_WG_LAUNCH(G)                                                                                               \
         if (d->dtype == PSG_BF16) hipLaunchKernelGGL((wgrad_kernel<bf16_t, G>), dim3(grid), dim3(256), 4 * 64 * 256, s, p); \
         else hipLaunchKernelGGL((wgrad_kernel<float, G>), dim3(grid), dim3(256), 4 * 32 * 512, s, p);
-        if (p.wide) {
+        if (p.wide == 3) {
+            constexpr int PL = 4 * 32768 + 1024;
+            if (p.bws) {
+                if (geom == 1) hipLaunchKernelGGL((wgrad_pipe_kernel<1, true>), dim3(grid), dim3(256), PL, s, p);
+                else hipLaunchKernelGGL((wgrad_pipe_kernel<2, true>), dim3(grid), dim3(256), PL, s, p);
+            } else {
+                if (geom == 1) hipLaunchKernelGGL((wgrad_pipe_kernel<1, false>), dim3(grid), dim3(256), PL, s, p);
+                else hipLaunchKernelGGL((wgrad_pipe_kernel<2, false>), dim3(grid), dim3(256), PL, s, p);
+            }
+        } else if (p.wide) {
             if (geom == 1) hipLaunchKernelGGL((wgrad_wide_kernel<1>), dim3(grid), dim3(256), 2 * (8192 + 16384), s, p);
             else hipLaunchKernelGGL((wgrad_wide_kernel<2>), dim3(grid), dim3(256), 2 * (8192 + 16384), s, p);
         } else if (p.BR == 160) {

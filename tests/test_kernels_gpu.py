@@ -741,3 +741,37 @@ def test_conv_splitk_matches_unsplit(psg, dtype, B, H, Cin, Cout, ks, stride):
         assert maxrel(outs[True][i], refv) < tol, what + " (split) vs CPU"
         # same products, another fp32 summation order (and one rounding to the output dtype)
         assert maxrel(outs[True][i], outs[False][i]) < (2e-5 if dtype == torch.float32 else 1.6e-2), what + " split vs unsplit"
+
+
+# (B, H, Cin, Cout, ks): Cout % 320 == 0, the (tap, ci) axis a multiple of 192, >= 40 tiles of 320 x 192 and NO bias gradient in
+# the launch: the software-pipelined one-wave-per-SIMD kernel (ring of four stages).  Pixel counts chosen to give 1, 2, 3, 4, 5,
+# 7 and many K steps (prologue / steady state / tail paths), M not a multiple of 32, borders at every map width, 1x1 layers.
+PIPE_CASES = [(2, 4, 1280, 640, 3), (4, 4, 1280, 640, 3), (6, 4, 1024, 320, 3), (2, 7, 1280, 640, 3), (3, 7, 1024, 320, 3), (1, 14, 1280, 640, 3),
+              (5, 14, 1024, 320, 3), (2, 27, 1024, 320, 3), (3, 9, 1920, 1280, 1), (33, 7, 1280, 640, 3)]
+
+
+@pytest.mark.parametrize("with_bias", [False, True], ids=["nobias", "bias"])
+@pytest.mark.parametrize("B,H,Cin,Cout,ks", PIPE_CASES)
+def test_wgrad_pipe_tiles(psg, B, H, Cin, Cout, ks, with_bias):
+    from pokemon_sprite_generator_amd import ops
+    dtype = torch.bfloat16
+    pad = 1 if ks == 3 else 0
+    name = f"pipe{B}.{H}.{Cin}.{Cout}.{ks}"
+    x = _q(h((B, Cin, H, H), name + "x", 1.2), dtype)
+    w = _q(h((Cout, Cin, ks, ks), name + "w", math.sqrt(3.0 / (Cin * ks * ks))), dtype).requires_grad_(True)
+    b = h((Cout,), name + "b", 0.2).requires_grad_(True)
+    ref = F.conv2d(x, w, b if with_bias else None, padding=pad)
+    gy = _q(h(tuple(ref.shape), name + "gy", 1.0), dtype)
+    ref.backward(gy)
+    xd = to_cl(x, dtype).to(DEV)
+    for layout in ("oihw", "ohwi"):
+        wd = w.detach().to(DEV)
+        if layout == "ohwi" and ks == 3:
+            wd = wd.contiguous(memory_format=torch.channels_last)
+        wd = torch.nn.Parameter(wd)
+        bd = torch.nn.Parameter(b.detach().to(DEV)) if with_bias else None
+        y = ops.conv2d(xd, wd, bd)
+        y.backward(to_cl(gy, dtype).to(DEV))
+        assert maxrel(wd.grad.cpu(), w.grad) < 1e-4 and rel_l2(wd.grad.cpu(), w.grad) < 1e-5, f"wgrad ({layout})"
+        if with_bias:
+            assert maxrel(bd.grad.cpu(), b.grad) < 1e-4, f"bias gradient ({layout})"
