@@ -697,15 +697,24 @@ __global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgP p) {
         lds_dma16(yrs, stage_base + pc * APASS, a_voff[pc]);
         a_voff[pc] += a_step;
     };
+    // Validity of a staged X piece WITHOUT compares: every condition is a difference whose sign bit says "outside", the sign
+    // bits are OR-ed and moved into bit 31 of the offset (>= 2^31 = out of range for the buffer load).  The compare / s_or /
+    // v_cndmask form made a serial VALU -> VCC -> SALU chain of ~16 instructions per piece; this is ~8 independent VALU ops.
+    // The (m mod HoWo, m mod Wo) trackers wrap with an unsigned min instead of compare + select.
+    const int v_rm_lo = b_in ? rm_lo : 0x3FFFFFFF;                 // (a lane with nothing to fetch: always "outside")
+    const int v_rm_hi = rm_lo + (int)rm_rng, v_wo_hi = wo_lo + (int)w_rng;
     auto x_track = [&](int j) -> uint32_t {
         const int po = 16 * (j >> 1) + 4 * (j & 1);
-        bool ok = b_in && g_mB < p.M - po;
+        int bad = (p.M - po - 1) - g_mB;                            // pixel beyond M
         if constexpr (GEOM == 1) {
-            ok = ok && (unsigned)(g_rm[j] - rm_lo) <= rm_rng && (unsigned)(g_wo[j] - wo_lo) <= w_rng;
-            int rm = g_rm[j] + st_rm; rm -= rm >= HoWo ? HoWo : 0; g_rm[j] = rm;
-            int wo = g_wo[j] + st_wo; wo -= wo >= p.Wo ? p.Wo : 0; g_wo[j] = wo;
+            bad |= (g_rm[j] - v_rm_lo) | (v_rm_hi - g_rm[j]) | (g_wo[j] - wo_lo) | (v_wo_hi - g_wo[j]);
+            const int t = g_rm[j] + (st_rm - HoWo), u = g_wo[j] + (st_wo - p.Wo);
+            g_rm[j] = (int)min((unsigned)t, (unsigned)(t + HoWo));
+            g_wo[j] = (int)min((unsigned)u, (unsigned)(u + p.Wo));
+        } else {
+            bad |= b_in ? 0 : -1;
         }
-        return ok ? (uint32_t)g_b : OOB;
+        return (uint32_t)g_b | ((uint32_t)bad & 0x80000000u);
     };
     auto x_issue = [&](int j, uint32_t boff, uint32_t stage_base) {
         const int po = 16 * (j >> 1) + 4 * (j & 1);
@@ -837,12 +846,15 @@ __global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgP p) {
     // (a step has 6 X fragments, so fragment 0 of every tile sits in bf0)
     int b = 0, st = 0;
     for (; st + 4 < nsteps; st += 2) {                 // steady state: tiles st+1 .. st+4 all exist
+#ifndef PSG_PIPE_EXP
+#define PSG_PIPE_EXP 0
+#endif
         kstep(std::true_type{}, afA, afB, b, (b + 1) & 3, (b + 3) & 3, true, true);
-        wait_vmcnt<9>();                               // tile st+2 landed; tile st+3 (just requested) may fly
-        __syncthreads();
+        if (PSG_PIPE_EXP == 2) wait_vmcnt<18>(); else wait_vmcnt<9>();                               // tile st+2 landed; tile st+3 (just requested) may fly
+        if (PSG_PIPE_EXP != 1) __syncthreads();
         kstep(std::true_type{}, afB, afA, (b + 1) & 3, (b + 2) & 3, b, true, true);
-        wait_vmcnt<9>();
-        __syncthreads();
+        if (PSG_PIPE_EXP == 2) wait_vmcnt<18>(); else wait_vmcnt<9>();
+        if (PSG_PIPE_EXP != 1) __syncthreads();
         b = (b + 2) & 3;
     }
     for (; st < nsteps; st += 2) {                     // the last (up to four) steps
