@@ -326,10 +326,11 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
             const int delta = ((dh * p.Wi + dw) * (int)p.ldx + t_c0 * CH) * ESZ;                 // wave-uniform
 #pragma unroll
             for (int j = 0; j < JX; ++j) {
+                // (inside-the-image test without compares: the sign bits of the four differences, OR-ed, go into bit 31 of
+                //  the offset = out of range for the buffer load; no VALU -> VCC -> select chain per piece)
                 const int sh = x_hb[j] + dh, sw = x_wb[j] + dw;
-                const bool ok = (unsigned)sh < (unsigned)p.Hi && (unsigned)sw < (unsigned)p.Wi;
-                uint32_t off = (uint32_t)(x_base[j] + delta);
-                off = ok ? off : OOB;
+                const int bad = sh | (p.Hi - 1 - sh) | sw | (p.Wi - 1 - sw);
+                const uint32_t off = (uint32_t)(x_base[j] + delta) | ((uint32_t)bad & OOB);
                 lds_dma16(xrs, xdst + j * PASS_BYTES, off);
             }
             if (++t_kh == p.ntap) { t_kh = 0; t_c0 += 8; }       // taps innermost, as in modes 0/1
@@ -339,9 +340,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
 #pragma unroll
             for (int j = 0; j < JX; ++j) {
                 const int sh = x_hb[j] + sgn * t_kh, sw = x_wb[j] + sgn * t_kw;
-                const bool ok = (unsigned)sh < (unsigned)p.Hi && (unsigned)sw < (unsigned)p.Wi;
-                uint32_t off = (uint32_t)(x_base[j] + delta);
-                off = ok ? off : OOB;
+                const int bad = sh | (p.Hi - 1 - sh) | sw | (p.Wi - 1 - sw);
+                const uint32_t off = (uint32_t)(x_base[j] + delta) | ((uint32_t)bad & OOB);
                 lds_dma16(xrs, xdst + j * PASS_BYTES, off);
             }
             if (++t_kw == p.ks) { t_kw = 0; if (++t_kh == p.ks) { t_kh = 0; t_c0 += 8; } }

@@ -195,15 +195,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgP p) {
         } else {
 #pragma unroll
             for (int j = 0; j < NPASS; ++j) {
-                const bool m_ok = g_m < p.M - RPP * j;
-                const uint32_t aoff = (m_ok && a_ok) ? (uint32_t)g_a : OOB;
-                bool ok = m_ok && b_in;
+                // (validity without compares: sign bits of the differences OR-ed into bit 31 of the offset - wgrad_pipe_kernel)
+                const int m_bad = (p.M - RPP * j - 1) - g_m;
+                const uint32_t aoff = (uint32_t)g_a | ((uint32_t)(m_bad | (a_ok ? 0 : -1)) & 0x80000000u);
+                int bad = m_bad | (b_in ? 0 : -1);
                 if constexpr (GEOM == 1) {
-                    ok = ok && (unsigned)(g_rm[j] - rm_lo) <= rm_rng && (unsigned)(g_wo[j] - wo_lo) <= w_rng;
-                    int rm = g_rm[j] + st_rm; rm -= rm >= HoWo ? HoWo : 0; g_rm[j] = rm;
-                    int wo = g_wo[j] + st_wo; wo -= wo >= p.Wo ? p.Wo : 0; g_wo[j] = wo;
+                    bad |= (g_rm[j] - rm_lo) | (rm_lo + (int)rm_rng - g_rm[j]) | (g_wo[j] - wo_lo) | (wo_lo + (int)w_rng - g_wo[j]);
+                    const int t = g_rm[j] + (st_rm - HoWo), u = g_wo[j] + (st_wo - p.Wo);
+                    g_rm[j] = (int)min((unsigned)t, (unsigned)(t + HoWo));
+                    g_wo[j] = (int)min((unsigned)u, (unsigned)(u + p.Wo));
                 }
-                const uint32_t boff = ok ? (uint32_t)g_b : OOB;
+                const uint32_t boff = (uint32_t)g_b | ((uint32_t)bad & 0x80000000u);
                 if constexpr (BR == 128) lds_dma16s(yrs, adst + j * PASS_BYTES, aoff, (uint32_t)(j * a_pass));
                 lds_dma16s(xrs_g, bdst + j * PASS_BYTES, boff, (uint32_t)(j * b_pass));
             }
@@ -474,25 +476,32 @@ __global__ __launch_bounds__(256, 2) void wgrad_wide_kernel(const WgP p) {
         g_wo[j] = g_rm[j] % p.Wo;
     }
     const int a_step = BKP * lddyB, b_step = BKP * ldxB;
+    // (validity without compares: see wgrad_pipe_kernel's x_track - sign bits of the differences OR-ed into bit 31 of the offset)
+    const int v_rm_lo = b_in ? rm_lo : 0x3FFFFFFF;
+    const int v_rm_hi = rm_lo + (int)rm_rng, v_wo_hi = wo_lo + (int)w_rng;
+    const int a_bad = a_ok ? 0 : -1;
     auto load_tiles = [&](int buf) {
         const uint32_t adst = lds_wave + (uint32_t)buf * STAGE;
         const uint32_t bdst = adst + AREG;
 #pragma unroll
         for (int j = 0; j < NPA; ++j) {
-            const bool m_ok = g_mA < p.M - 16 * j;
-            const uint32_t aoff = (m_ok && a_ok) ? (uint32_t)g_a : OOB;
+            const int bad = ((p.M - 16 * j - 1) - g_mA) | a_bad;
+            const uint32_t aoff = (uint32_t)g_a | ((uint32_t)bad & 0x80000000u);
             lds_dma16s(yrs, adst + j * PASS_BYTES, aoff, (uint32_t)(16 * j * lddyB));
         }
 #pragma unroll
         for (int j = 0; j < NPB; ++j) {
             const int po = 16 * (j >> 1) + 4 * (j & 1);
-            bool ok = b_in && g_mB < p.M - po;
+            int bad = (p.M - po - 1) - g_mB;
             if constexpr (GEOM == 1) {
-                ok = ok && (unsigned)(g_rm[j] - rm_lo) <= rm_rng && (unsigned)(g_wo[j] - wo_lo) <= w_rng;
-                int rm = g_rm[j] + st_rm; rm -= rm >= HoWo ? HoWo : 0; g_rm[j] = rm;
-                int wo = g_wo[j] + st_wo; wo -= wo >= p.Wo ? p.Wo : 0; g_wo[j] = wo;
+                bad |= (g_rm[j] - v_rm_lo) | (v_rm_hi - g_rm[j]) | (g_wo[j] - wo_lo) | (v_wo_hi - g_wo[j]);
+                const int t = g_rm[j] + (st_rm - HoWo), u = g_wo[j] + (st_wo - p.Wo);
+                g_rm[j] = (int)min((unsigned)t, (unsigned)(t + HoWo));
+                g_wo[j] = (int)min((unsigned)u, (unsigned)(u + p.Wo));
+            } else {
+                bad |= b_in ? 0 : -1;
             }
-            const uint32_t boff = ok ? (uint32_t)g_b : OOB;
+            const uint32_t boff = (uint32_t)g_b | ((uint32_t)bad & 0x80000000u);
             lds_dma16s(xrs_g, bdst + j * PASS_BYTES, boff, (uint32_t)(po * ldxB));
         }
         g_mA += BKP; g_mB += BKP; g_a += a_step; g_b += b_step;
