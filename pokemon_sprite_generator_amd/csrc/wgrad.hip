@@ -818,6 +818,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgP p) {
         };
         auto cat = [&](s16x4 a, s16x4 c) { s16x8 v = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]}; return *reinterpret_cast<bf16x8*>(&v); };
         s16x4 w0 = {0, 0, 0, 0}, w1 = {0, 0, 0, 0};
+        // the ones operand is written by hand, two MFMAs ahead of its use: left to the compiler it is a constant that may get
+        // rematerialised (v_mov) directly in front of the asm MFMA reading it - a VALU-write -> MFMA-read hazard the hazard
+        // recogniser cannot see through the asm (seen with a second bias fragment: garbage sums; tools/mfma_hazard_check.py
+        // looks for this pattern in the -S dump)
+        u32x4 onesw = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int j = 0; j < 6; ++j) {
             bf16x8& bc = (j & 1) ? bf1 : bf0;
@@ -842,6 +847,11 @@ __global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgP p) {
                 if (i == 7 && issue && xj >= 0) xoff = x_track(xj);
                 if (i == 8 && issue && xj >= 0) x_issue(xj, xoff, ibase);
                 if constexpr (BIAS) {                  // (groups 3 / 4 have the lightest slices)
+                    if (j == 4 && i == 7) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) asm volatile("v_mov_b32 %0, 0x3f803f80" : "=v"(onesw[e]));
+                    }
+                    const bf16x8 ones = *reinterpret_cast<const bf16x8*>(&onesw);
                     if (j == 3 && i == 8) w0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sb + biasoff));
                     if (j == 3 && i == 9) w1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(sb + biasoff + 4 * AROWB));
                     if (j == 4 && i == 9) { const bf16x8 wf = cat(w0, w1); asm("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(accb) : "v"(wf), "v"(ones)); }
@@ -855,15 +865,12 @@ __global__ __launch_bounds__(256, 1) void wgrad_pipe_kernel(const WgP p) {
     // (a step has 6 X fragments, so fragment 0 of every tile sits in bf0)
     int b = 0, st = 0;
     for (; st + 4 < nsteps; st += 2) {                 // steady state: tiles st+1 .. st+4 all exist
-#ifndef PSG_PIPE_EXP
-#define PSG_PIPE_EXP 0
-#endif
         kstep(std::true_type{}, afA, afB, b, (b + 1) & 3, (b + 3) & 3, true, true);
-        if (PSG_PIPE_EXP == 2) wait_vmcnt<18>(); else wait_vmcnt<9>();                               // tile st+2 landed; tile st+3 (just requested) may fly
-        if (PSG_PIPE_EXP != 1) __syncthreads();
+        wait_vmcnt<9>();                               // tile st+2 landed; tile st+3 (just requested) may fly
+        __syncthreads();
         kstep(std::true_type{}, afB, afA, (b + 1) & 3, (b + 2) & 3, b, true, true);
-        if (PSG_PIPE_EXP == 2) wait_vmcnt<18>(); else wait_vmcnt<9>();
-        if (PSG_PIPE_EXP != 1) __syncthreads();
+        wait_vmcnt<9>();
+        __syncthreads();
         b = (b + 2) & 3;
     }
     for (; st < nsteps; st += 2) {                     // the last (up to four) steps

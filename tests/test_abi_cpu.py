@@ -96,3 +96,20 @@ def test_product_has_no_cpu_fallback():
         if f.endswith(".py"):
             src += open(os.path.join(pkg, f)).read()
     assert "import oracle" not in src and "from oracle" not in src, "the product must never import the oracle"
+
+
+def test_inline_asm_mfmas_have_no_valu_write_hazard(tmp_path):
+    """wgrad_pipe_kernel issues its MFMAs as inline asm (accumulators pinned to AGPRs), which hides them from hipcc's hazard
+    recogniser: a VALU write of a source VGPR directly in front of one gets no wait states (round 3: a rematerialised ones
+    operand turned the bias sums into garbage).  tools/mfma_hazard_check.py scans the ISA of the shipped build flags for it."""
+    import subprocess, sys
+    hipcc = "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc")
+    asm = str(tmp_path / "wgrad.s")
+    src = os.path.join(ROOT, "pokemon_sprite_generator_amd", "csrc", "wgrad.hip")
+    subprocess.run([hipcc, "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-S", "--cuda-device-only", src, "-o", asm],
+                   check=True, capture_output=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mfma_hazard_check.py"), asm, "wgrad_pipe_kernel"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert " 0 hazards" in r.stdout and not r.stdout.startswith("0 MFMAs"), r.stdout

@@ -747,7 +747,8 @@ def test_conv_splitk_matches_unsplit(psg, dtype, B, H, Cin, Cout, ks, stride):
 # the launch: the software-pipelined one-wave-per-SIMD kernel (ring of four stages).  Pixel counts chosen to give 1, 2, 3, 4, 5,
 # 7 and many K steps (prologue / steady state / tail paths), M not a multiple of 32, borders at every map width, 1x1 layers.
 PIPE_CASES = [(2, 4, 1280, 640, 3), (4, 4, 1280, 640, 3), (6, 4, 1024, 320, 3), (2, 7, 1280, 640, 3), (3, 7, 1024, 320, 3), (1, 14, 1280, 640, 3),
-              (5, 14, 1024, 320, 3), (2, 27, 1024, 320, 3), (3, 9, 1920, 1280, 1), (33, 7, 1280, 640, 3)]
+              (5, 14, 1024, 320, 3), (2, 27, 1024, 320, 3), (3, 9, 1920, 1280, 1), (33, 7, 1280, 640, 3),
+              (3, 9, 1888, 1280, 1)]          # (the last: a ragged last q tile, 32 of its 192 columns beyond Cin)
 
 
 @pytest.mark.parametrize("with_bias", [False, True], ids=["nobias", "bias"])
