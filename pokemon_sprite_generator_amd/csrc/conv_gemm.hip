@@ -81,6 +81,9 @@ static int choose_and_launch(const ConvP& p0, int dtype, hipStream_t s) {
     if (pl.splits > 1 && p.ws != nullptr && (int64_t)pl.splits * p.M * p.N * 4 <= p.ws_bytes) {
         p.splits = pl.splits; p.kt_per_split = pl.kt_per_split;
     }
+#ifdef PSG_ABL
+    if (PSG_ABL & 8) { const char* e = getenv("PSG_DBG_PTR"); p.ws = (e && p.splits <= 1) ? reinterpret_cast<float*>(strtoull(e, nullptr, 0)) : (p.splits <= 1 ? nullptr : p.ws); }
+#endif
     {
         static int dbg = -1;                               // PSG_CONV_DEBUG=1: print the tile chosen for every launch
         if (dbg < 0) { const char* e = getenv("PSG_CONV_DEBUG"); dbg = e ? atoi(e) : 0; }

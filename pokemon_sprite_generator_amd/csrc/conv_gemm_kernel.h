@@ -230,6 +230,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave & 1, wm = wave >> 1;
+    // Ablation / timeline builds (tools/build_abl.sh; never the shipped library): PSG_ABL bit 0 = one K step only, bit 1 = no
+    // epilogue, bit 3 = per-workgroup phase timestamps into the buffer PSG_DBG_PTR names (tools/conv_timeline.py)
+#ifndef PSG_ABL
+#define PSG_ABL 0
+#endif
+    uint64_t* dbg = nullptr;
+    if ((PSG_ABL & 8) && !SPLITK && p.ws) { dbg = reinterpret_cast<uint64_t*>(p.ws) + (size_t)blockIdx.x * 8; if (tid == 0) { dbg[0] = wall_clock64(); dbg[5] = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)); dbg[6] = __builtin_amdgcn_s_getreg(6 | (0 << 6) | (7 << 11)); } }
 
     // ---- XCD-aware tile id + grouped raster -------------------------------
     int mt, nt, split = 0;
@@ -298,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
 
     // this workgroup's K steps [kt0, kt1) (the whole K axis unless split-K)
     const int kt0 = SPLITK ? split * p.kt_per_split : 0;
-    const int kt1 = SPLITK ? min(p.KT, kt0 + p.kt_per_split) : p.KT;
+    const int kt1 = (PSG_ABL & 1) ? kt0 + 1 : (SPLITK ? min(p.KT, kt0 + p.kt_per_split) : p.KT);
     // uniform tap state of the NEXT K step to load (fast modes): chunk offset inside the tap, kh, kw - at step kt0 of the
     // taps-innermost walk (MODE 3: t_kh indexes the class's tap table)
     int t_c0 = 0, t_kh = 0, t_kw = 0;
@@ -475,6 +482,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
     }
     wait_vmcnt<0>();
     __syncthreads();                       // the DMA of tile 0 has landed for every wave
+    if ((PSG_ABL & 8) && dbg && tid == 0) dbg[1] = wall_clock64();
     for (int kt = kt0; kt + 1 < kt1; ++kt) {
         const int buf = (kt - kt0) & 1;
         // buffer buf^1 was last read in step kt-1, which every wave finished before the barrier below
@@ -534,14 +542,28 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
                 const int idx = it * 64 + lane;
                 const int row = idx / E_CPRW, chk = idx - row * E_CPRW;
                 const int mt_ = m0 + wm * WM + row, n = n0 + wn * WN + chk * 8;
-                const uint4 z4 = {0u, 0u, 0u, 0u};
-                res_row[it] = (idx < E_NCH && mt_ < p.M && n < p.N)
-                                  ? *reinterpret_cast<const uint4*>(resg + (int64_t)conv_out_m<MODE>(p, mt_) * ldaux + n) : z4;
+                // (an unconditional load from a clamped address + a select on the VALUE: as `ok ? *ptr : zero` hipcc selected
+                //  between the pointer and the address of a zero in scratch memory and issued a flat load)
+                const bool ok = idx < E_NCH && mt_ < p.M && n < p.N;
+                const uint4 got = *reinterpret_cast<const uint4*>(resg + (ok ? (int64_t)conv_out_m<MODE>(p, mt_) * ldaux + n : (int64_t)0));
+                res_row[it].x = ok ? got.x : 0u; res_row[it].y = ok ? got.y : 0u; res_row[it].z = ok ? got.z : 0u; res_row[it].w = ok ? got.w : 0u;
             }
         }
     }
     compute((kt1 - 1 - kt0) & 1);
+    if (PSG_ABL & 2) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+#pragma unroll
+            for (int j = 0; j < NB; ++j)
+#pragma unroll
+                for (int e = 0; e < AE; ++e) sacc += acc[i][j][e];
+        if (sacc == 12345.678f) reinterpret_cast<float*>(p.y)[tid] = sacc;
+        return;
+    }
     __syncthreads();                       // every wave is done with the tile buffers: the epilogue reuses them
+    if ((PSG_ABL & 8) && dbg && tid == 0) dbg[2] = wall_clock64();
 
     // ---- fused epilogue: phase 1 loads every bias / residual operand of the tile, phase 2 computes and stores ----
     const uint64_t dseed = p.drop_seed + ((p.drop_thresh && p.seed_dev) ? *p.seed_dev : 0ull);     // wave-uniform
@@ -559,6 +581,82 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
             constexpr int NCH = WM * CPRW;                     // chunks per sub-tile
             constexpr int NIT = (NCH + 63) / 64;
             char* reg = smem + wave * (WM * PITCH);
+            // The epilogue runs once per workgroup as straight-line code with nothing to hide behind (both workgroups of a CU
+            // reach it together: tools/conv_timeline.py), so its INSTRUCTION COUNT is its time: ~850 instructions took 2.6 us of
+            // a 13 us K = 640 tile.  Two things made most of them: a per-cell exec-mask branch around each per-sample-add load
+            // (taken or not, ~10 instructions per cell, and the taken form waited for every load on its own), and a flush loop
+            // that predicated, read LDS, waited and built a 64-bit address once per store.
+            // (a) per-sample add of pixel row j: ONE wave-uniform branch; inside it the loads are unconditional (clamped to a
+            //     valid address) and batched, the validity test is a select afterwards
+            auto load_ra = [&](int j, f32x4 (&ra4)[NA]) {
+                if (rag) {
+                    const bool rok = rows[j] >= 0;
+                    const T* rp = rag + (int64_t)(rok ? smp[j] : 0) * p.ldra;
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) {
+                        const int n = n0 + wn * WN + i * 16 + 4 * kq;
+                        ra4[i] = load4<T>(rp + (n < p.N ? n : 0));
+                    }
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) {
+                        const int n = n0 + wn * WN + i * 16 + 4 * kq;
+                        if (!(rok && n < p.N)) ra4[i] = zero4;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) ra4[i] = zero4;
+                }
+            };
+            // (b) flush of NITX x 64 row-major 16-byte chunks of the wave's region (rows of PITCHX bytes, the first one tile row
+            //     `rbase` of the wave's sub-tile) to `dst`: a tile that lies wholly inside y (wave-uniform test; every tile of
+            //     the U-Net's training shapes) reads all chunks first and stores them through one 64-bit row base + 32-bit
+            //     offsets, without predicates
+            const bool tile_full = MODE != 3 && m0 + BM <= p.M && n0 + BN <= p.N;
+            auto flush_rows = [&](auto nchx_c, const char* src, int rbase, T* dst, int64_t ldd) {
+                constexpr int NCHX = decltype(nchx_c)::value, NITX = (NCHX + 63) / 64;
+                if (tile_full) {
+                    T* base = dst + (int64_t)(m0 + wm * WM + rbase) * ldd + (n0 + wn * WN);
+                    constexpr int G = 4;                            // chunks in flight per lane (registers: the accumulators may still be live)
+                    constexpr bool REG = 64 % CPRW == 0;            // (64-wide sub-tiles: iteration `it` is rows it*8 .. it*8+7, same chunk per lane)
+                    T* lane0 = base + (uint32_t)((lane / CPRW) * (int)ldd + (lane % CPRW) * 8);
+#pragma unroll
+                    for (int g0 = 0; g0 < NITX; g0 += G) {
+                        uint4 v0, v1, v2, v3;
+                        auto rd = [&](int it) {
+                            const int idx = it * 64 + lane;
+                            const int row = idx / CPRW, chk = idx - row * CPRW;
+                            return *reinterpret_cast<const uint4*>(src + (NCHX % 64 == 0 || idx < NCHX ? row : 0) * PITCH + chk * 16);
+                        };
+                        auto wr = [&](int it, const uint4& v) {
+                            const int idx = it * 64 + lane;
+                            const int row = idx / CPRW, chk = idx - row * CPRW;
+                            T* d = REG ? lane0 + (int64_t)(it * (64 / CPRW)) * ldd : base + (uint32_t)(row * (int)ldd + chk * 8);
+                            if (NCHX % 64 == 0 || idx < NCHX) *reinterpret_cast<uint4*>(d) = v;
+                        };
+                        if (g0 + 0 < NITX) v0 = rd(g0 + 0);
+                        if (g0 + 1 < NITX) v1 = rd(g0 + 1);
+                        if (g0 + 2 < NITX) v2 = rd(g0 + 2);
+                        if (g0 + 3 < NITX) v3 = rd(g0 + 3);
+                        if (g0 + 0 < NITX) wr(g0 + 0, v0);
+                        if (g0 + 1 < NITX) wr(g0 + 1, v1);
+                        if (g0 + 2 < NITX) wr(g0 + 2, v2);
+                        if (g0 + 3 < NITX) wr(g0 + 3, v3);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                } else {
+#pragma unroll
+                    for (int it = 0; it < NITX; ++it) {
+                        const int idx = it * 64 + lane;
+                        const int row = idx / CPRW, chk = idx - row * CPRW;
+                        const int mt_ = m0 + wm * WM + rbase + row, n = n0 + wn * WN + chk * 8;
+                        if (idx < NCHX && mt_ < p.M && n < p.N) {
+                            const uint4 val = *reinterpret_cast<const uint4*>(src + row * PITCH + chk * 16);
+                            *reinterpret_cast<uint4*>(dst + (int64_t)conv_out_m<MODE>(p, mt_) * ldd + n) = val;
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            };
             auto epilogue = [&](auto ek_c) {
             constexpr int EK = decltype(ek_c)::value;
             auto stage_and_flush = [&](auto pass_c) {
@@ -574,11 +672,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
                     f32x4 ra4[NA];
-#pragma unroll
-                    for (int i = 0; i < NA; ++i) {
-                        const int n = n0 + wn * WN + i * 16 + 4 * kq;
-                        ra4[i] = (rag && rows[j] >= 0 && n < p.N) ? load4<T>(rag + (int64_t)smp[j] * p.ldra + n) : zero4;
-                    }
+                    load_ra(j, ra4);
 #pragma unroll
                     for (int i = 0; i < NA; ++i) {
                         const int n = n0 + wn * WN + i * 16 + 4 * kq;
@@ -596,19 +690,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
                     }
                     __builtin_amdgcn_sched_barrier(0);          // one pixel row of tiles at a time (register pressure)
                 }
-                T* dst = reinterpret_cast<T*>(PASS == 0 ? p.preact : p.y);
-                const int64_t ldd = PASS == 0 ? p.ldpre : p.ldy;
-#pragma unroll
-                for (int it = 0; it < NIT; ++it) {
-                    const int idx = it * 64 + lane;
-                    const int row = idx / CPRW, chk = idx - row * CPRW;
-                    const int mt_ = m0 + wm * WM + row, n = n0 + wn * WN + chk * 8;
-                    if (idx < NCH && mt_ < p.M && n < p.N) {
-                        const uint4 val = *reinterpret_cast<const uint4*>(reg + row * PITCH + chk * 16);
-                        *reinterpret_cast<uint4*>(dst + (int64_t)conv_out_m<MODE>(p, mt_) * ldd + n) = val;
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
+                if ((PSG_ABL & 8) && dbg && tid == 0) dbg[7] = wall_clock64();
+                flush_rows(std::integral_constant<int, NCH>{}, reg, 0, reinterpret_cast<T*>(PASS == 0 ? p.preact : p.y), PASS == 0 ? p.ldpre : p.ldy);
             };
             // `preact` AND y without a residual (the FFN's first GEMM: GELU value + saved derivative): one evaluation of the
             // epilogue per element instead of one per pass - the sub-tile goes out in two halves of WM/2 pixels, each half
@@ -625,11 +708,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
                     for (int jj = 0; jj < NBH; ++jj) {
                         const int j = h * NBH + jj;
                         f32x4 ra4[NA];
-#pragma unroll
-                        for (int i = 0; i < NA; ++i) {
-                            const int n = n0 + wn * WN + i * 16 + 4 * kq;
-                            ra4[i] = (rag && rows[j] >= 0 && n < p.N) ? load4<T>(rag + (int64_t)smp[j] * p.ldra + n) : zero4;
-                        }
+                        load_ra(j, ra4);
 #pragma unroll
                         for (int i = 0; i < NA; ++i) {
                             const int n = n0 + wn * WN + i * 16 + 4 * kq;
@@ -644,20 +723,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
-#pragma unroll
-                    for (int it = 0; it < NITH; ++it) {
-                        const int idx = it * 64 + lane;
-                        const int row = idx / CPRW, chk = idx - row * CPRW;
-                        const int mt_ = m0 + wm * WM + h * HR + row, n = n0 + wn * WN + chk * 8;
-                        if (idx < NCHH && mt_ < p.M && n < p.N) {
-                            const int64_t m = conv_out_m<MODE>(p, mt_);
-                            const uint4 a = *reinterpret_cast<const uint4*>(reg + row * PITCH + chk * 16);
-                            const uint4 b = *reinterpret_cast<const uint4*>(regB + row * PITCH + chk * 16);
-                            *reinterpret_cast<uint4*>(dpre + m * p.ldpre + n) = a;
-                            *reinterpret_cast<uint4*>(dy + m * p.ldy + n) = b;
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
+                    flush_rows(std::integral_constant<int, NCHH>{}, reg, h * HR, dpre, p.ldpre);
+                    flush_rows(std::integral_constant<int, NCHH>{}, regB, h * HR, dy, p.ldy);
                 }
             };
             // A residual (or EK_DMUL's saved derivative) WITHOUT `preact`: the operand was fetched row-major (res_row, issued in
@@ -678,11 +745,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
                     for (int jj = 0; jj < NBH; ++jj) {
                         const int j = h * NBH + jj;
                         f32x4 ra4[NA];
-#pragma unroll
-                        for (int i = 0; i < NA; ++i) {
-                            const int n = n0 + wn * WN + i * 16 + 4 * kq;
-                            ra4[i] = (rag && rows[j] >= 0 && n < p.N) ? load4<T>(rag + (int64_t)smp[j] * p.ldra + n) : zero4;
-                        }
+                        load_ra(j, ra4);
 #pragma unroll
                         for (int i = 0; i < NA; ++i) {
                             const int n = n0 + wn * WN + i * 16 + 4 * kq;
@@ -693,27 +756,47 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
                         }
                         __builtin_amdgcn_sched_barrier(0);
                     }
+                    auto join = [&](const f32x4 lo, const f32x4 hi, const uint4 a) {
+                        const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+                        bf16x8 o;
 #pragma unroll
-                    for (int it = 0; it < NITH; ++it) {
-                        const int idx = it * 64 + lane;              // chunk inside the half: same (row, chunk) walk as res_row
-                        const int row = idx / CPRW, chk = idx - row * CPRW;
-                        const int mt_ = m0 + wm * WM + h * HR + row, n = n0 + wn * WN + chk * 8;
-                        if (mt_ < p.M && n < p.N) {
-                            const f32x4 lo = *reinterpret_cast<const f32x4*>(reg + row * PITCHF + chk * 32);
-                            const f32x4 hi = *reinterpret_cast<const f32x4*>(reg + row * PITCHF + chk * 32 + 16);
-                            const uint4 a = res_row[h * NITH + it];
-                            const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
-                            bf16x8 o;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float a0 = __uint_as_float(aw[e] << 16), a1 = __uint_as_float(aw[e] & 0xFFFF0000u);
-                                const float v0 = e < 2 ? lo[2 * e] : hi[2 * e - 4], v1 = e < 2 ? lo[2 * e + 1] : hi[2 * e - 3];
-                                o[2 * e] = (bf16_t)conv_aux_k<EK>(p, v0, a0);
-                                o[2 * e + 1] = (bf16_t)conv_aux_k<EK>(p, v1, a1);
-                            }
-                            *reinterpret_cast<bf16x8*>(dy + (int64_t)conv_out_m<MODE>(p, mt_) * p.ldy + n) = o;
+                        for (int e = 0; e < 4; ++e) {
+                            const float a0 = __uint_as_float(aw[e] << 16), a1 = __uint_as_float(aw[e] & 0xFFFF0000u);
+                            const float v0 = e < 2 ? lo[2 * e] : hi[2 * e - 4], v1 = e < 2 ? lo[2 * e + 1] : hi[2 * e - 3];
+                            o[2 * e] = (bf16_t)conv_aux_k<EK>(p, v0, a0);
+                            o[2 * e + 1] = (bf16_t)conv_aux_k<EK>(p, v1, a1);
                         }
-                        __builtin_amdgcn_sched_barrier(0);
+                        return o;
+                    };
+                    if (tile_full) {                                 // (as flush_rows: all reads first, one row base, no predicates)
+                        T* base = dy + (int64_t)(m0 + wm * WM + h * HR) * p.ldy + (n0 + wn * WN);
+                        f32x4 lo[NITH], hi[NITH];
+#pragma unroll
+                        for (int it = 0; it < NITH; ++it) {
+                            const int idx = it * 64 + lane;
+                            const int row = idx / CPRW, chk = idx - row * CPRW;
+                            lo[it] = *reinterpret_cast<const f32x4*>(reg + row * PITCHF + chk * 32);
+                            hi[it] = *reinterpret_cast<const f32x4*>(reg + row * PITCHF + chk * 32 + 16);
+                        }
+#pragma unroll
+                        for (int it = 0; it < NITH; ++it) {
+                            const int idx = it * 64 + lane;
+                            const int row = idx / CPRW, chk = idx - row * CPRW;
+                            *reinterpret_cast<bf16x8*>(base + (uint32_t)(row * (int)p.ldy + chk * 8)) = join(lo[it], hi[it], res_row[h * NITH + it]);
+                        }
+                    } else {
+#pragma unroll
+                        for (int it = 0; it < NITH; ++it) {
+                            const int idx = it * 64 + lane;              // chunk inside the half: same (row, chunk) walk as res_row
+                            const int row = idx / CPRW, chk = idx - row * CPRW;
+                            const int mt_ = m0 + wm * WM + h * HR + row, n = n0 + wn * WN + chk * 8;
+                            if (mt_ < p.M && n < p.N) {
+                                const f32x4 lo = *reinterpret_cast<const f32x4*>(reg + row * PITCHF + chk * 32);
+                                const f32x4 hi = *reinterpret_cast<const f32x4*>(reg + row * PITCHF + chk * 32 + 16);
+                                *reinterpret_cast<bf16x8*>(dy + (int64_t)conv_out_m<MODE>(p, mt_) * p.ldy + n) = join(lo, hi, res_row[h * NITH + it]);
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
                 }
             };
@@ -742,6 +825,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
                 case EK_DMUL: epilogue(std::integral_constant<int, EK_DMUL>{}); break;
                 default: epilogue(std::integral_constant<int, EK_GENERIC>{}); break;
             }
+            if ((PSG_ABL & 8) && dbg) { if (tid == 0) dbg[3] = wall_clock64(); wait_vmcnt<0>(); __syncthreads(); if (tid == 0) dbg[4] = wall_clock64(); }
             return;
         }
 #pragma unroll
