@@ -276,6 +276,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
     int x_hb[JX], x_wb[JX], x_base[JX];   // tap-0 source row / col, and byte offset of that pixel (+ chunk sc)
     {
         const int HoWo = p.Ho * p.Wo;
+        const bool small_m = p.M < (1 << 24);
+        const float inv_howo = 1.0f / (float)HoWo, inv_wo = 1.0f / (float)p.Wo;
 #pragma unroll
         for (int j = 0; j < JX; ++j) {
             const int m = m0 + sr + RPP * j;
@@ -293,8 +295,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
                 x_hb[j] = 0; x_wb[j] = 0;
                 x_base[j] = m * (int)p.ldx * ESZ + sc * 16;
             } else if (m < p.M) {
-                const int b = m / HoWo, rm = m - b * HoWo;
-                const int ho = rm / p.Wo, wo = rm - ho * p.Wo;
+                // (float-reciprocal division, exact below 2^24: the two integer divisions per staging pass were a visible part
+                //  of every 3x3 tile's start - tools/conv_timeline.py)
+                const int b = small_m ? fastdiv(m, HoWo, inv_howo) : m / HoWo, rm = m - b * HoWo;
+                const int ho = small_m ? fastdiv(rm, p.Wo, inv_wo) : rm / p.Wo, wo = rm - ho * p.Wo;
                 if (p.transposed) { x_hb[j] = ho + p.pad; x_wb[j] = wo + p.pad; }
                 else { x_hb[j] = ho * p.stride - p.pad; x_wb[j] = wo * p.stride - p.pad; }
                 if (MODE == 2) x_base[j] = b * p.Hi * p.Wi;                       // pixel base only
@@ -550,6 +554,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
             }
         }
     }
+    const uint64_t dseed = p.drop_seed + ((p.drop_thresh && p.seed_dev) ? *p.seed_dev : 0ull);     // wave-uniform (requested here: flies under the last step)
     compute((kt1 - 1 - kt0) & 1);
     if (PSG_ABL & 2) {
         float sacc = 0.f;
@@ -566,7 +571,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
     if ((PSG_ABL & 8) && dbg && tid == 0) dbg[2] = wall_clock64();
 
     // ---- fused epilogue: phase 1 loads every bias / residual operand of the tile, phase 2 computes and stores ----
-    const uint64_t dseed = p.drop_seed + ((p.drop_thresh && p.seed_dev) ? *p.seed_dev : 0ull);     // wave-uniform
     if constexpr (FT16) {
         if (p.epi_lds) {
             // LDS-staged stores.  In the accumulator layout a lane owns 4 channels of one pixel, so a store instruction
