@@ -22,12 +22,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def family(name):
-    m = re.search(r"conv_gemm_kernelI.*?Li(\d+)ELi(\d+)ELi(\d)EEE", name)
+    m = re.search(r"conv_gemm_kernelI.*?Li(\d+)ELi(\d+)ELi(\d)E(?:Lb\dE)?EE", name)       # (<T, BM, BN, MODE[, SPLITK]>)
     if m:
         return "conv_gemm(fwd gather)" if m.group(3) in "02" else "conv_gemm(dgrad gather)"
     if "conv_gemm_kernel" in name:
         return "conv_gemm(?)"
-    if "wgrad_kernel" in name or "wgrad_wide_kernel" in name:
+    if "wgrad_kernel" in name or "wgrad_wide_kernel" in name or "wgrad_pipe_kernel" in name:
         return "wgrad"
     if "attn_" in name:
         return "attention"
