@@ -618,7 +618,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
             const bool tile_full = MODE != 3 && m0 + BM <= p.M && n0 + BN <= p.N;
             auto flush_rows = [&](auto nchx_c, const char* src, int rbase, T* dst, int64_t ldd) {
                 constexpr int NCHX = decltype(nchx_c)::value, NITX = (NCHX + 63) / 64;
-                if (tile_full) {
+                if (tile_full && ldd < (1 << 22)) {                 // (32-bit element offsets inside the tile: 128 rows x ldd)
                     T* base = dst + (int64_t)(m0 + wm * WM + rbase) * ldd + (n0 + wn * WN);
                     constexpr int G = 4;                            // chunks in flight per lane (registers: the accumulators may still be live)
                     constexpr bool REG = 64 % CPRW == 0;            // (64-wide sub-tiles: iteration `it` is rows it*8 .. it*8+7, same chunk per lane)
@@ -772,7 +772,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ConvP p) {
                         }
                         return o;
                     };
-                    if (tile_full) {                                 // (as flush_rows: all reads first, one row base, no predicates)
+                    if (tile_full && p.ldy < (1 << 22)) {            // (as flush_rows: all reads first, one row base, no predicates)
                         T* base = dy + (int64_t)(m0 + wm * WM + h * HR) * p.ldy + (n0 + wn * WN);
                         f32x4 lo[NITH], hi[NITH];
 #pragma unroll
