@@ -408,25 +408,28 @@ __global__ __launch_bounds__(256, (ND <= 5 ? 2 : 1)) void attn_dkv_mfma(const At
                 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kb, st, 0, 0, 0);    // S[q][key]
                 dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, vb, dp, 0, 0, 0);    // dP[q][key]
             }
+            // Per element this loop is the kernel's time (49 tile pairs x 16 elements per lane at L = 196: the vector ALU, not
+            // memory, bounds it), so it is branch-free and hashes along the query row: an absent query (l >= L) has zero Q / dO
+            // rows and (lse, delta) = 0 in the image - its P is finite and meets zero operands; an absent key's column is
+            // never stored.  Mask index (bh L + l) ceil(S/2) + key/2 = row base of the tile + (acc_row ceil(S/2) + key/2).
             f32x16 pd;
+            const uint32_t hS = (uint32_t)((p.S + 1) >> 1), koff = (uint32_t)(key >> 1);
+            const DropRow dr = drop_row(seed, ((uint64_t)bh * p.L + (uint64_t)(qt * 32)) * (uint64_t)hS);
+            const uint32_t t16 = p.drop_thresh >> 16;
+            const int hsh = (key & 1) ? 16 : 0;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int l = qt * 32 + acc_row(r, fh);
-                float pv = 0.f, ds = 0.f;
-                if (kok && l < p.L) {
-                    const float2 ld2 = *reinterpret_cast<const float2*>(Qs + l * STR + 2 * d);      // (lse, delta) of query l
-                    const float pr = __expf(st[r] * p.scale - ld2.x);
-                    float dpr = dp[r];
-                    pv = pr;
-                    if (p.drop_thresh) {
-                        const uint32_t hh = drop_hash_pair(seed, ((uint64_t)bh * p.L + l) * (uint64_t)((p.S + 1) >> 1) + (uint32_t)(key >> 1));
-                        const bool keep = drop_keep_half(hh, key & 1, p.drop_thresh);
-                        pv = keep ? pr * p.drop_scale : 0.f;
-                        dpr = keep ? dpr * p.drop_scale : 0.f;
-                    }
-                    ds = pr * (dpr - ld2.y) * p.scale;
+                const float2 ld2 = *reinterpret_cast<const float2*>(Qs + l * STR + 2 * d);      // (lse, delta) of query l
+                const float pr = __expf(st[r] * p.scale - ld2.x);
+                float dpr = dp[r], pv = pr;
+                if (p.drop_thresh) {                       // (wave-uniform)
+                    const uint32_t hh = drop_hash_row(dr, (uint32_t)acc_row(r, fh) * hS + koff);
+                    const bool keep = ((hh >> hsh) & 0xFFFFu) >= t16;
+                    pv = keep ? pr * p.drop_scale : 0.f;
+                    dpr = keep ? dpr * p.drop_scale : 0.f;
                 }
-                pd[r] = pv; st[r] = ds;
+                pd[r] = pv; st[r] = pr * (dpr - ld2.y) * p.scale;
             }
             const bf16x8 pf0 = pack8(pd, 0), pf1 = pack8(pd, 1), sf0 = pack8(st, 0), sf1 = pack8(st, 1);
 #pragma unroll
