@@ -300,6 +300,10 @@ int psg_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const v
  * 160 / 320, 16-byte aligned rows), by the VALU kernels (other shapes) and by the exact-fp32 MFMA kernels (fp32, head_dim
  * 16 / 32 / 64 / 80 / 160 while K/V - and Q/dO for backward - fit LDS).  All paths draw the same dropout mask. */
 int psg_attn_path_counts(int64_t* mfma, int64_t* valu, int64_t* mfma_f32);
+/* Diagnostic: which kernel families later psg_attn_fwd / psg_attn_bwd calls may take: bit 0 the bf16 MFMA kernels, bit 1
+ * the exact-fp32 MFMA kernels; a cleared bit sends those launches to the VALU kernels (default 3).  The parity tests pin
+ * each family against the same reference this way (a process-wide switch: not for concurrent use). */
+int psg_attn_set_paths(int allow_mask);
 /* delta: fp32 [B, heads, L] scratch.  dq/dk/dv have the strides of q/k/v. */
 int psg_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const void* v, int64_t ldv,
                  const void* o, int64_t ldo, const void* dout, int64_t lddo, const float* lse,

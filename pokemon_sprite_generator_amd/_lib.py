@@ -90,6 +90,7 @@ SIGNATURES = {
     "psg_attn_fwd": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_int64, c_void_p]
                      + [c_int] * 5 + [c_float, c_float, c_uint64, c_int, c_void_p]),
     "psg_attn_path_counts": (c_int, [c_void_p, c_void_p, c_void_p]),
+    "psg_attn_set_paths": (c_int, [c_int]),
     "psg_attn_bwd": (c_int, [c_void_p, c_int64] * 5 + [c_void_p, c_void_p] + [c_void_p, c_int64] * 3
                      + [c_int] * 5 + [c_float, c_float, c_uint64, c_int, c_void_p]),
     "psg_sumsq_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int, c_void_p, c_void_p]),

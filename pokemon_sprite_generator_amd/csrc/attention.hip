@@ -400,6 +400,8 @@ static int f32_mfma_on() {
     if (on < 0) { const char* e = getenv("PSG_ATTN_F32_MFMA"); on = (e && atoi(e) == 0) ? 0 : 1; }
     return on;
 }
+static int g_attn_allow = 3;                         // psg_attn_set_paths: bit 0 bf16 MFMA, bit 1 exact-fp32 MFMA
+int psg_attn_set_paths(int allow_mask) { g_attn_allow = allow_mask & 3; return PSG_OK; }
 int psg_attn_path_counts(int64_t* mfma, int64_t* valu, int64_t* mfma_f32) {
     if (mfma) *mfma = g_attn_paths[0];
     if (valu) *valu = g_attn_paths[1];
@@ -422,11 +424,11 @@ int psg_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const v
     p.drop_thresh = drop_p > 0.f ? drop_thresh(drop_p) : 0u; p.drop_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f; p.seed = seed; p.seed_dev = seed_source();
     dim3 grid((L + AT_Q - 1) / AT_Q, B * heads);
     ProfScope prof(PROF_ATTN, 4.0 * (double)B * heads * L * S * d, (hipStream_t)stream);
-    if (attn_mfma_applicable(L, S, d, dtype, ldq, ldk, ldv, ldo) && aligned16(q) && aligned16(k) && aligned16(v) && aligned8(o)) {
+    if ((g_attn_allow & 1) && attn_mfma_applicable(L, S, d, dtype, ldq, ldk, ldv, ldo) && aligned16(q) && aligned16(k) && aligned16(v) && aligned8(o)) {
         ++g_attn_paths[0];
         return attn_mfma_fwd(to_mfma(p), (hipStream_t)stream);
     }
-    if (f32_mfma_on() && attn_f32_applicable(L, S, d, dtype, ldq, ldk, ldv, ldo) && aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o)) {
+    if ((g_attn_allow & 2) && f32_mfma_on() && attn_f32_applicable(L, S, d, dtype, ldq, ldk, ldv, ldo) && aligned16(q) && aligned16(k) && aligned16(v) && aligned16(o)) {
         ++g_attn_paths[2];
         return attn_f32_fwd(to_f32(p), (hipStream_t)stream);
     }
@@ -460,12 +462,12 @@ int psg_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const v
     const int gdelta = (int)((rows + 3) / 4);
     dim3 gq((L + AT_Q - 1) / AT_Q, B * heads), gkv((S + AT_Q - 1) / AT_Q, B * heads);
     ProfScope prof(PROF_ATTN, 10.0 * (double)B * heads * L * S * d, s);
-    if (attn_mfma_applicable(L, S, d, dtype, ldq, ldk, ldv, ldo) && ((lddo | lddq | lddk | lddv) & 7) == 0 && aligned16(q) && aligned16(k) &&
+    if ((g_attn_allow & 1) && attn_mfma_applicable(L, S, d, dtype, ldq, ldk, ldv, ldo) && ((lddo | lddq | lddk | lddv) & 7) == 0 && aligned16(q) && aligned16(k) &&
         aligned16(v) && aligned16(o) && aligned16(dout) && aligned8(dq) && aligned8(dk) && aligned8(dv)) {
         ++g_attn_paths[0];
         return attn_mfma_bwd(to_mfma(p), s);       // (delta is produced inside the dQ kernel)
     }
-    if (f32_mfma_on() && attn_f32_applicable(L, S, d, dtype, ldq, ldk, ldv, ldo) && ((lddo | lddq | lddk | lddv) & 3) == 0 && aligned16(q) &&
+    if ((g_attn_allow & 2) && f32_mfma_on() && attn_f32_applicable(L, S, d, dtype, ldq, ldk, ldv, ldo) && ((lddo | lddq | lddk | lddv) & 3) == 0 && aligned16(q) &&
         aligned16(k) && aligned16(v) && aligned16(o) && aligned16(dout) && aligned16(dq) && aligned16(dk) && aligned16(dv)) {
         ++g_attn_paths[2];
         return attn_f32_bwd(to_f32(p), s);          // (delta is produced inside the dQ kernel)

@@ -525,6 +525,154 @@ def test_attention_dropout_statistics(psg):
     assert 0.5 * 0.05 / (0.95 * L) < float(o.var()) < 2.0 * 0.05 / (0.95 * L)
 
 
+# ---------------------------------------------------------------- train-mode (dropout ON) gradient parity
+# The benchmarked step runs with p = 0.05 on the attention probabilities and twice in the FFN.  The masks are a stateless
+# hash of (seed, element index) REGENERATED inside the backward kernels, so a wrong row base / key offset there gives
+# plausible-looking wrong gradients that no self-comparison sees.  These tests read the forward's keep-mask off probe
+# launches (the mask depends on seed and geometry only, never on the values), build the torch fp32 reference
+#   O = (softmax(QK^T/sqrt(d)) * keep / (1-p)) V          (torch/nn/functional.py: dropout on the probabilities)
+# with that mask and compare o, dq, dk, dv - per kernel family (bf16 MFMA, exact-fp32 MFMA, VALU via psg_attn_set_paths).
+ATTN_DROP_CASES = [  # B, heads, L, S, d, self   (unet.py:160-173 at 8 heads: d 80/160; the CLI's 4 heads: d 320)
+    (2, 8, 196, 196, 80, True), (2, 8, 196, 32, 80, False), (2, 8, 49, 49, 160, True), (2, 8, 49, 32, 160, False),
+    (2, 8, 16, 16, 160, True), (2, 8, 16, 32, 160, False), (2, 4, 49, 49, 320, True), (1, 4, 49, 20, 320, False),
+    (1, 4, 49, 21, 80, False),                       # odd S: the pair hash's last key has no partner
+]
+
+
+def _attn_set_paths(mask):
+    from pokemon_sprite_generator_amd import _lib
+    _lib.check(_lib.init(0).psg_attn_set_paths(int(mask)), "psg_attn_set_paths")
+
+
+def _attn_keep_mask(ops, B, heads, L, S, d, self_mode, p, seed, dtype):
+    """keep[b, h, l, s] of the forward's dropout mask: q = k = 0 -> uniform probabilities 1/S; v = key one-hot columns,
+    d keys per probe launch -> output column j of a query row is (1/S)/(1-p) where key c0+j was kept, 0 where dropped."""
+    E = heads * d
+    keep = torch.zeros(B, heads, L, S, dtype=torch.bool)
+    for c0 in range(0, S, d):
+        n = min(d, S - c0)
+        if self_mode:
+            src = torch.zeros(B, L, 3 * E)
+            vv = src[..., 2 * E:]
+        else:
+            q = torch.zeros(B, L, E)
+            src = torch.zeros(B, S, 2 * E)
+            vv = src[..., E:]
+        for hh in range(heads):
+            for j in range(n):
+                vv[:, c0 + j, hh * d + j] = 1.0
+        with torch.no_grad():
+            if self_mode:
+                o = ops.attention_self(src.to(dtype).to(DEV), heads, p, seed)
+            else:
+                o = ops.attention_cross(q.to(dtype).to(DEV), src.to(dtype).to(DEV), heads, p, seed)
+        keep[..., c0:c0 + n] = (o.float().cpu().view(B, L, heads, d)[..., :n] > 0).permute(0, 2, 1, 3)
+    return keep
+
+
+def _attn_ref_drop(q, k, v, heads, keep, p):
+    B, L, E = q.shape
+    S, d = k.shape[1], E // heads
+    qh = q.view(B, L, heads, d).transpose(1, 2) * math.sqrt(1.0 / d)
+    kh = k.view(B, S, heads, d).transpose(1, 2)
+    vh = v.view(B, S, heads, d).transpose(1, 2)
+    pr = torch.softmax(qh @ kh.transpose(-2, -1), dim=-1) * keep.to(q.dtype) / (1.0 - p)
+    return (pr @ vh).transpose(1, 2).reshape(B, L, E)
+
+
+@pytest.mark.parametrize("path", ["mfma_bf16", "mfma_f32", "valu_f32", "valu_bf16"])
+@pytest.mark.parametrize("B,heads,L,S,d,self_mode", ATTN_DROP_CASES)
+def test_attention_backward_with_dropout(psg, path, B, heads, L, S, d, self_mode):
+    from pokemon_sprite_generator_amd import ops
+    dtype = torch.bfloat16 if path.endswith("bf16") else torch.float32
+    col = {"mfma_bf16": 0, "valu_f32": 1, "valu_bf16": 1, "mfma_f32": 2}[path]
+    if path == "mfma_f32" and d > 160:
+        pytest.skip("fp32 head_dim 320 has no exact-fp32 MFMA kernel (K, V do not fit LDS): the VALU case covers it")
+    p, seed = 0.3, 24680 + 7 * L + S
+    E = heads * d
+    name = f"atd{B}.{heads}.{L}.{S}.{d}"
+    _attn_set_paths(0 if path.startswith("valu") else 3)
+    try:
+        keep = _attn_keep_mask(ops, B, heads, L, S, d, self_mode, p, seed, dtype)
+        rate = float(keep.float().mean())
+        assert abs(rate - (1 - p)) < 0.03, rate
+        if self_mode:
+            qkv = _q(h((B, L, 3 * E), name, 1.0), dtype).requires_grad_(True)
+            ref = _attn_ref_drop(qkv[..., :E], qkv[..., E:2 * E], qkv[..., 2 * E:], heads, keep, p)
+        else:
+            qs = _q(h((B, L, E), name + "q", 1.0), dtype).requires_grad_(True)
+            kv = _q(h((B, S, 2 * E), name + "kv", 1.0), dtype).requires_grad_(True)
+            ref = _attn_ref_drop(qs, kv[..., :E], kv[..., E:], heads, keep, p)
+        go = _q(h((B, L, E), name + "g", 1.0), dtype)
+        ref.backward(go)
+        before = _attn_paths()
+        if self_mode:
+            qd = qkv.detach().to(dtype).to(DEV).requires_grad_(True)
+            o = ops.attention_self(qd, heads, p, seed)
+            o.backward(go.to(dtype).to(DEV))
+            got = [("o", o, ref), ("dqkv", qd.grad, qkv.grad), ("dq", qd.grad[..., :E], qkv.grad[..., :E]),
+                   ("dk", qd.grad[..., E:2 * E], qkv.grad[..., E:2 * E]), ("dv", qd.grad[..., 2 * E:], qkv.grad[..., 2 * E:])]
+        else:
+            qd = qs.detach().to(dtype).to(DEV).requires_grad_(True)
+            kd = kv.detach().to(dtype).to(DEV).requires_grad_(True)
+            o = ops.attention_cross(qd, kd, heads, p, seed)
+            o.backward(go.to(dtype).to(DEV))
+            got = [("o", o, ref), ("dq", qd.grad, qs.grad), ("dk", kd.grad[..., :E], kv.grad[..., :E]), ("dv", kd.grad[..., E:], kv.grad[..., E:])]
+        after = _attn_paths()
+        for c in range(3):                            # forward + backward both ran on the family under test
+            assert after[c] - before[c] == (2 if c == col else 0), (path, before, after)
+        tol = TOL[dtype]                              # the bars of test_attention (dropout off)
+        for what, a, b in got:
+            assert maxrel(a.float().cpu(), b) < (tol if what == "o" else tol * 2), (path, what, maxrel(a.float().cpu(), b))
+    finally:
+        _attn_set_paths(3)
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,C", [(2 * 196, 640), (300, 256)])
+def test_ffn_gelu_dropout_backward(psg, dtype, M, C):
+    """The fused FFN node in TRAIN mode (unet.py:176-187,250): y = x + 0.6 * drop2(W2 drop1(gelu(W1 x + b1)) + b2) with p = 0.3.
+    Covers the GELU + dropout + saved-derivative epilogue (EK_GELU_DROP, PSG_CONV_SAVE_DACT / DACT_MUL) and the second
+    dropout's regenerated mask (psg_epilogue_bwd) against torch autograd with the masks read off probe launches."""
+    from pokemon_sprite_generator_amd import ops
+    p, s1, s2, alpha = 0.3, 1357, 2468, 0.6
+    Hd = 2 * C
+    nm = f"ffd{M}.{C}"
+    # probes: the mask is a function of (seed, element index) only
+    with torch.no_grad():
+        ones1 = torch.ones(Hd, device=DEV)
+        z1 = ops.linear(torch.zeros(M, C, device=DEV, dtype=dtype), torch.zeros(Hd, C, device=DEV), ones1, act=ops.ACT_GELU, drop_p=p, seed=s1)
+        m1 = (z1.float().cpu() > 0)
+        z2 = ops.linear(torch.zeros(M, Hd, device=DEV, dtype=dtype), torch.zeros(C, Hd, device=DEV), torch.ones(C, device=DEV), drop_p=p, seed=s2)
+        m2 = (z2.float().cpu() > 0)
+    assert abs(float(m1.float().mean()) - (1 - p)) < 0.02 and abs(float(m2.float().mean()) - (1 - p)) < 0.02
+    assert not torch.equal(m1[:, :C], m2)
+    x = _q(h((M, C), nm + "x", 1.0), dtype).requires_grad_(True)
+    w1 = _q(h((Hd, C), nm + "w1", math.sqrt(3.0 / C)), dtype).requires_grad_(True)
+    b1 = h((Hd,), nm + "b1", 0.3).requires_grad_(True)
+    w2 = _q(h((C, Hd), nm + "w2", math.sqrt(3.0 / Hd)), dtype).requires_grad_(True)
+    b2 = h((C,), nm + "b2", 0.3).requires_grad_(True)
+    gy = _q(h((M, C), nm + "g", 1.0), dtype)
+    hm = F.gelu(F.linear(x, w1, b1)) * m1.float() / (1 - p)
+    if dtype == torch.bfloat16:
+        hm = hm + (hm.detach().bfloat16().float() - hm.detach())       # the kernel stores the hidden activation in bf16 (straight-through)
+    ref = x + alpha * (F.linear(hm, w2, b2) * m2.float() / (1 - p))
+    ref.backward(gy)
+    dv = [t.detach().to(DEV).requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    dv[0] = x.detach().to(dtype).to(DEV).requires_grad_(True)
+    y = ops.ffn(dv[0], dv[1], dv[2], dv[3], dv[4], alpha, drop_p=p, seed1=s1, seed2=s2)
+    y.backward(gy.to(dtype).to(DEV))
+    tol = TOL[dtype]
+    assert maxrel(y.float().cpu(), ref) < tol, "y"
+    for what, a, b in (("dx", dv[0].grad, x.grad), ("dw1", dv[1].grad, w1.grad), ("db1", dv[2].grad, b1.grad),
+                       ("dw2", dv[3].grad, w2.grad), ("db2", dv[4].grad, b2.grad)):
+        assert maxrel(a.float().cpu(), b) < tol * 2, (what, maxrel(a.float().cpu(), b))
+    # exactly the dropped hidden units / outputs carry no gradient: db2 only sums kept outputs (checked above through the
+    # reference); and the output equals the input wherever the second mask dropped
+    dropped = ~m2
+    assert torch.equal(y.float().cpu()[dropped], x.detach()[dropped])
+
+
 # ---------------------------------------------------------------- optimizer
 def test_sumsq_adamw_clip(psg):
     from pokemon_sprite_generator_amd import FusedAdamW, GradArena

@@ -586,3 +586,51 @@ def test_gradient_batch_linearity_b64(dtype):
     assert worst < bar, (worst_name, worst)
     assert len(zero) == 0, zero                   # every one of the 478 parameters received a gradient
     st.close()
+
+
+def test_gradient_batch_linearity_b256():
+    """BASELINE configs[2] at ITS size (per-GPU batch 256, bf16): tile choice, split decisions, the XCD raster and the 32-bit
+    in-tile offset guard are batch-dependent, so the benchmark's own shapes get a gradient check: the arena of ONE batch-256
+    backward == the mean of the arenas of four batch-64 backwards over the same samples (the regime
+    test_gradient_batch_linearity_b64 ties to the reference fixtures).  Dividing by 4 is exact; eval mode (dropout masks
+    are per launch)."""
+    import pokemon_sprite_generator_amd as psg
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(0)
+    B, Bs = 256, 64
+    unet = psg.UNet(compute_dtype=torch.bfloat16).to(dev)
+    with torch.no_grad():
+        for name, p in unet.named_parameters():
+            if p.dim() == 2 and ("out_proj" in name or "ffn.3" in name or "time_proj" in name or "text_proj" in name):
+                p.mul_(25.0)
+    st = psg.DiffusionStepper(unet, psg.NoiseScheduler(), distributed=False)
+    unet.eval()
+    g = torch.Generator(device=dev).manual_seed(5)
+    lat = torch.randn(B, 8, 27, 27, device=dev, generator=g) * 1.2
+    txt = torch.randn(B, 32, 256, device=dev, generator=g)
+    t = torch.randint(0, 1000, (B,), device=dev, generator=g)
+    nz = torch.randn(B, 8, 27, 27, device=dev, generator=g)
+    loss256 = _fwd_bwd(psg, unet, st, lat, txt, t, nz)
+    big = st.arena.flat.clone()
+    assert bool(torch.isfinite(big).all())
+    acc = torch.zeros_like(big, dtype=torch.float64)
+    lsum = 0.0
+    for i in range(0, B, Bs):
+        sl = slice(i, i + Bs)
+        lsum += _fwd_bwd(psg, unet, st, lat[sl], txt[sl], t[sl], nz[sl])
+        acc += st.arena.flat
+    mean = (acc / (B // Bs)).float()
+    assert abs(lsum / (B // Bs) - loss256) < 1e-5 * max(1.0, abs(loss256))
+    worst, worst_name, zero = 0.0, None, []
+    for (name, p), off in zip([(n, q) for n, q in unet.named_parameters() if q.requires_grad], st.arena.offsets):
+        a, b = big[off:off + p.numel()].double(), mean[off:off + p.numel()].double()
+        nb = float(b.norm())
+        if nb == 0.0:
+            zero.append(name)
+            continue
+        e = float((a - b).norm()) / nb
+        if e > worst:
+            worst, worst_name = e, name
+    assert worst < 4e-2, (worst_name, worst)      # the bf16 bar of the batch-64 test
+    assert len(zero) == 0, zero
+    st.close()
