@@ -247,6 +247,10 @@ def main():
                                                             "over gloo (default batch 8, 2 steps); everything else - launch_ranks, the "
                                                             "rendezvous, the bucketed all-reduce of the full 640 M-gradient arena, the "
                                                             "max-over-ranks timing, the JSON line - is the production path")
+    ap.add_argument("--force-ddp", action="store_true", help="--gpus 1 only: a process group of ONE rank over RCCL (backend nccl); the "
+                                                             "bucketed all-reduce (ncclAvg, async work handles on the side stream, "
+                                                             "launched from the bucket-ready callbacks during backward) and the NaN-flag "
+                                                             "MAX reduce really execute - the exchange is the identity, its cost is not")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] / configs[4] legs of the default run")
     ap.add_argument("--dry-run", action="store_true", help="rendezvous check only: the ranks meet over gloo on the CPU, all-reduce a 1 "
                                                            "and rank 0 prints the world size (no GPU; tests/test_bench_cpu.py)")
@@ -281,7 +285,11 @@ def run_worker(args):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     nccl_world, backend = 1, None
-    if world > 1:
+    force_ddp = bool(args.force_ddp) and world == 1
+    if force_ddp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+    if world > 1 or force_ddp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.rehearse:                                # one GPU, N processes: gloo moves the buckets through the host
             backend = "gloo"
@@ -306,12 +314,12 @@ def run_worker(args):
     torch.manual_seed(1234)                      # (replicas are made equal by the stepper's rank-0 broadcast, not by this)
     unet = psg.UNet(latent_dim=8, text_dim=256, time_emb_dim=128, num_heads=8, compute_dtype=dtype).to(dev)
     stepper = psg.DiffusionStepper(unet, psg.NoiseScheduler(), lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01, eps=1e-6,
-                                   max_grad_norm=1.0, distributed=(world > 1),
+                                   max_grad_norm=1.0, distributed=("force" if force_ddp else world > 1),
                                    grad_bucket_dtype=torch.bfloat16 if args.grad_bucket_dtype == "bf16" else torch.float32)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)          # every rank draws its own shard
 
     def barrier():
-        if world > 1:
+        if world > 1 or force_ddp:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -364,7 +372,7 @@ def run_worker(args):
         barrier()
         el = time.perf_counter() - t0
         tmax = torch.tensor([el], device=dev, dtype=torch.float64)
-        if world > 1:
+        if world > 1 or force_ddp:
             torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
         return float(tmax.item()), out
 
@@ -498,6 +506,8 @@ def run_worker(args):
             res["allreduce_buckets"] = len(stepper.reducer.buckets)
             res["allreduce_buckets_launched_during_backward"] = stepper.reducer.launched_early
             res["allreduce_avg_in_collective"] = stepper.reducer.avg_in_collective
+        if force_ddp:
+            res["force_ddp"] = "process group of ONE rank over RCCL: every collective of the data-parallel step executes (identity exchange)"
         if args.rehearse:
             res["rehearsal"] = "N workers on ONE GPU over gloo: plumbing check, not a throughput figure"
         if fam:
@@ -511,7 +521,7 @@ def run_worker(args):
             except Exception as e:                      # noqa: BLE001
                 res["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if world > 1 or force_ddp:
         torch.distributed.destroy_process_group()
 
 

@@ -123,11 +123,16 @@ class ShardedLoader:
 
 
 class BucketedAllReduce:
+    """`force_single`: run the collectives even in a group of ONE rank (the exchange is the identity there).  That is how
+    the RCCL code path - communicator, ncclAvg, bf16 buckets, async work handles on the side stream - executes on a 1-GPU
+    box: `DiffusionStepper(distributed="force")`, `bench.py --gpus 1 --force-ddp`, tests/test_ddp_gpu.py."""
+
     def __init__(self, arena_flat, params, offsets, bucket_bytes=64 << 20, process_group=None, overlap=True,
-                 bucket_dtype=torch.float32):
+                 bucket_dtype=torch.float32, force_single=False):
         self.flat = arena_flat
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (bool(force_single) and dist.is_initialized())
         self.overlap = overlap and self.flat.is_cuda
         if bucket_dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("BucketedAllReduce: bucket_dtype must be float32 or bfloat16")
@@ -166,7 +171,7 @@ class BucketedAllReduce:
         others inside it): the local answer comes from the library version (ncclAvg exists since NCCL 2.10; RCCL reports
         its NCCL API level), and the ranks then agree on the MINIMUM of their answers through a plain SUM-free MIN
         all-reduce that every backend supports, so a mixed installation falls back together."""
-        if not (dist.is_available() and dist.is_initialized()) or self.world <= 1 or dist.get_backend(group) != "nccl":
+        if not (dist.is_available() and dist.is_initialized()) or not self.active or dist.get_backend(group) != "nccl":
             return False
         try:
             ver = torch.cuda.nccl.version()
@@ -188,7 +193,7 @@ class BucketedAllReduce:
 
     def on_ready(self, i):
         """Called (by the gradient sink) when parameter i's gradient is final for this step."""
-        if self.world == 1 or not self.overlap:
+        if not self.active or not self.overlap:
             return
         b = self._bucket_of[i]
         self._pending[b] -= 1
@@ -219,7 +224,7 @@ class BucketedAllReduce:
 
     def finish(self):
         """Complete the exchange: launch buckets not yet sent, wait, and average."""
-        if self.world == 1:
+        if not self.active:
             return
         for b in range(len(self.buckets)):
             if self._pending[b] != 0 or not self.overlap:

@@ -68,8 +68,14 @@ class DiffusionStepper:
             raise _lib.PsgError("DiffusionStepper needs the U-Net on a GPU (HIP path only)")
         self.lib = _lib.init(self.device.index if self.device.index is not None else torch.cuda.current_device())
         self.reducer = None
+        # distributed="force": run the gradient exchange and the flag reduce even in a process group of ONE rank (the RCCL
+        # path on a 1-GPU box; the step's results are those of the non-distributed step bit for bit)
+        force_single = distributed == "force"
+        if force_single and not (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            raise _lib.PsgError('DiffusionStepper(distributed="force") needs an initialised process group')
         if distributed is None:
             distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
+        distributed = bool(distributed)
         self.params = ParamArena(unet.parameters())        # flat fp32 masters, conv weights OHWI
         if distributed:
             self.params.broadcast(src=0)                    # replicas equal by construction, not by RNG seeding
@@ -83,7 +89,7 @@ class DiffusionStepper:
         else:
             self.optimizer = torch.optim.Adam(self.arena.params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self.reducer = BucketedAllReduce(self.arena.flat, self.arena.params, self.arena.offsets, bucket_bytes,
-                                         bucket_dtype=grad_bucket_dtype) if distributed else None
+                                         bucket_dtype=grad_bucket_dtype, force_single=force_single) if distributed else None
         self.flag = torch.zeros(1, dtype=torch.int32, device=self.device)      # bits: enum psg_flag (include/psg_hip.h)
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.criterion_beta = 0.1                                               # nn.SmoothL1Loss(beta=0.1) :300

@@ -279,3 +279,95 @@ def test_bench_rehearsal_two_ranks_one_gpu():
     assert j["allreduce_buckets_launched_during_backward"] >= j["allreduce_buckets"] - 1
     assert j["nan_flag"] == 0 and j["final_loss"] > 0 and j["value"] > 0
     assert "roofline" in j and "rehearsal" in j
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# RCCL itself, on the one GPU this pool has: a process group of ONE rank over backend "nccl".  Every collective of the
+# data-parallel step really executes on the RCCL communicator - parameter broadcast, the ncclAvg decision (MIN all-reduce),
+# the bucketed async all-reduce (ReduceOp.AVG on fp32 and bf16 buckets) launched from the bucket-ready callbacks on the
+# side stream, the MAX reduce of the NaN flag - and, the exchange being the identity, the step must equal the
+# non-distributed step bit for bit (bf16 buckets: the gradient rounded once to bf16).
+# ---------------------------------------------------------------------------------------------------------------------
+def _rccl_world1_worker(port, q, bucket_dtype, full):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        import pokemon_sprite_generator_amd as psg
+        import pokemon_sprite_generator_amd.unet as U
+        bd = torch.bfloat16 if bucket_dtype == "bf16" else torch.float32
+
+        def run(distributed):
+            U._SeedStream.counter = 0               # TRAIN mode, dropout on: both runs draw the same per-site seeds (rank 0 both times)
+            if full:
+                torch.manual_seed(0)
+                model = psg.UNet(compute_dtype=torch.bfloat16).cuda()
+                lat, txt, t, nz = _full_batch()
+                kw = dict(lr=1e-3, weight_decay=0.0, max_grad_norm=1e9)
+            else:
+                model = _make()
+                lat, txt, t, nz = _batch()
+                kw = dict(lr=1e-3, weight_decay=0.0, max_grad_norm=1e9, bucket_bytes=1 << 16)
+            st = psg.DiffusionStepper(model, psg.NoiseScheduler(), distributed=distributed, grad_bucket_dtype=bd, **kw)
+            out = st.train_step(lat.cuda(), txt.cuda(), t.cuda(), nz.cuda())
+            torch.cuda.synchronize()
+            return st, out
+
+        st0, out0 = run(False)
+        g0, p0, l0 = st0.arena.flat.clone(), st0.params.flat.clone(), float(out0["loss"].item())
+        st0.close()
+        del st0
+        st1, out1 = run("force")
+        red = st1.reducer
+        g1, p1 = st1.arena.flat, st1.params.flat
+        want = g0 if bucket_dtype == "fp32" else g0.bfloat16().float()
+        q.put({"ok": True, "backend": dist.get_backend(), "world": red.world, "active": red.active, "avg": red.avg_in_collective,
+               "buckets": len(red.buckets), "early": red.launched_early, "bytes": red.bytes_per_step, "numel": int(st1.arena.numel),
+               "grads_equal": bool(torch.equal(g1, want)), "grad_err": float((g1 - want).abs().max()),
+               "params_equal": bool(torch.equal(p1, p0)) if bucket_dtype == "fp32" else None,
+               "loss0": l0, "loss1": float(out1["loss"].item()), "flag": int(out1["nan_flag"].item()),
+               "gnorm0": float(out0["grad_norm"].item()), "gnorm1": float(out1["grad_norm"].item()), "steps": st1.steps_done()})
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put({"ok": False, "err": traceback.format_exc()})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("bucket_dtype,full", [("fp32", False), ("bf16", False), ("fp32", True)], ids=["tiny-fp32", "tiny-bf16", "full-fp32"])
+def test_rccl_world1_step_is_the_single_process_step(bucket_dtype, full):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_world1_worker, args=(_free_port(), q, bucket_dtype, full))
+    p.start()
+    r = q.get(timeout=900)
+    p.join(timeout=120)
+    assert r["ok"], r.get("err")
+    assert r["backend"] == "nccl" and r["world"] == 1 and r["active"] and r["avg"], r           # ncclAvg inside the collective
+    assert r["buckets"] > 1 and r["early"] >= r["buckets"] - 1, r                                  # launched from the callbacks during backward
+    assert r["bytes"] == (4 if bucket_dtype == "fp32" else 2) * r["numel"]
+    if full:
+        assert 20 <= r["buckets"] <= 40 and N_PARAMS <= r["numel"] <= N_PARAMS + 8 * 478
+    assert r["flag"] == 0 and r["steps"] == 1 and r["loss0"] == r["loss1"]
+    assert r["grads_equal"], r["grad_err"]
+    if bucket_dtype == "fp32":
+        assert r["params_equal"] and r["gnorm0"] == r["gnorm1"]
+
+
+def test_bench_force_ddp_runs_rccl_on_one_gpu():
+    """`python bench.py --gpus 1 --force-ddp`: the driver's N = 1 command with the RCCL exchange switched on."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-ddp", "--no-cpu-baseline", "--no-secondary",
+                        "--no-profile", "--batch", "8", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+    assert j["n_gpus"] == 1 and j["nccl_world_size"] == 1 and j["collective_backend"] == "nccl" and "force_ddp" in j
+    assert j["allreduce_bytes_per_step"] >= 4 * N_PARAMS and j["allreduce_avg_in_collective"] is True
+    assert j["allreduce_buckets_launched_during_backward"] >= j["allreduce_buckets"] - 1
+    assert j["nan_flag"] == 0 and j["final_loss"] > 0
