@@ -344,6 +344,14 @@ int psg_clip_scale_f32(float* g, int64_t n, const float* normsq, float max_norm,
  * 3 attention, 4 GroupNorm): summed kernel milliseconds, summed algorithmic work (FLOPs for
  * 0-3, bytes for 4) and launch count.  Off by default: no cost on the product path.
  * ------------------------------------------------------------------------- */
+/* Planning input: the number of CUs the tile / split-K choosers of psg_conv_fwd and psg_conv_wgrad may count on (default
+ * 256 = the whole MI355X; 0 restores it).  A data-parallel step that overlaps the RCCL all-reduce with backward sets it to
+ * 256 minus the CUs the collective's channels occupy, so a launch planned as ONE round of workgroups does not become two. */
+int psg_set_available_cus(int n);
+/* Measurement helpers (tools/contention.py): a HIP stream restricted to n_cus CUs (hipExtStreamCreateWithCUMask; the CUs
+ * taken out are spread evenly over the 8 XCDs), to rehearse the step with part of the chip occupied by a collective. */
+int psg_stream_create_cu_mask(int n_cus, psg_stream_t* stream);
+int psg_stream_destroy(psg_stream_t stream);
 int psg_profile_begin(void);
 int psg_profile_end(double* ms, double* work, int64_t* launches, int nkinds);
 

@@ -97,6 +97,9 @@ SIGNATURES = {
     "psg_adamw_f32": (c_int, [c_void_p] * 4 + [c_int64] + [c_float] * 5 + [c_int, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "psg_adamw_dev_f32": (c_int, [c_void_p] * 4 + [c_int64, c_void_p, c_void_p, c_int] + [c_float] * 4 + [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "psg_clip_scale_f32": (c_int, [c_void_p, c_int64, c_void_p, c_float, c_void_p]),
+    "psg_set_available_cus": (c_int, [c_int]),
+    "psg_stream_create_cu_mask": (c_int, [c_int, c_void_p]),
+    "psg_stream_destroy": (c_int, [c_void_p]),
     "psg_profile_begin": (c_int, []),
     "psg_profile_end": (c_int, [c_void_p, c_void_p, c_void_p, c_int]),
 }

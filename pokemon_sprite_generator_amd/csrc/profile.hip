@@ -37,10 +37,37 @@ ProfScope::~ProfScope() {
     hipEventRecord(g_recs[idx_].b, stream_);
 }
 
+static int g_avail_cus = 256;
+int avail_cus() { return g_avail_cus; }
+
 }  // namespace psg
 using namespace psg;
 
 extern "C" {
+
+int psg_set_available_cus(int n) {
+    PSG_REQUIRE(n == 0 || (n >= 8 && n <= 256), PSG_ERR_ARG, "set_available_cus: %d", n);
+    g_avail_cus = n == 0 ? 256 : n;
+    return PSG_OK;
+}
+
+int psg_stream_create_cu_mask(int n_cus, psg_stream_t* stream) {
+    PSG_REQUIRE(stream && n_cus >= 8 && n_cus <= 256, PSG_ERR_ARG, "stream_create_cu_mask: n_cus %d", n_cus);
+    // take 256 - n_cus CUs out, spread evenly over the 8 XCDs under either numbering of the mask bits (XCD-major: bit i ->
+    // XCD i / 32; round-robin: bit i -> XCD i % 8): cleared bits 33 * j (mod 256)
+    uint32_t mask[8];
+    for (int i = 0; i < 8; ++i) mask[i] = 0xFFFFFFFFu;
+    for (int j = 0; j < 256 - n_cus; ++j) { const int bit = (33 * j) & 255; mask[bit >> 5] &= ~(1u << (bit & 31)); }
+    hipStream_t s = nullptr;
+    PSG_HIP_CHECK(hipExtStreamCreateWithCUMask(&s, 8, mask));
+    *stream = (psg_stream_t)s;
+    return PSG_OK;
+}
+
+int psg_stream_destroy(psg_stream_t stream) {
+    PSG_HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
+    return PSG_OK;
+}
 
 int psg_profile_begin(void) {
     std::lock_guard<std::mutex> lk(g_prof_mu);

@@ -46,6 +46,10 @@ struct ProfScope {
     hipStream_t stream_;
 };
 
+// CUs the tile choosers may count on (psg_set_available_cus; 256 unless part of the chip is taken, e.g. by an overlapped
+// RCCL all-reduce): a launch planned as ONE round of workgroups over 256 CUs becomes two when 16 of them are busy
+int avail_cus();
+
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }
 

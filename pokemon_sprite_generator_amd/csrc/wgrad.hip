@@ -991,7 +991,7 @@ static void wgrad_plan(const psg_wgrad_desc* d, WgP& p) {
         const int64_t tiles128 = (int64_t)((d->Cout + 127) / 128) * ((p.Q + 127) / 128);
         if (!off && d->dtype == PSG_BF16 && same && p.BR == 128 && q256 * 100 <= (int64_t)p.Q * 105 && tiles128 >= 200) { p.wide = 1; BKP = 32; }
     }
-    int kSlots = 512;
+    int kSlots = 2 * avail_cus();
     {
         // pipelined 320 x 256 tiles (one 256-thread workgroup per CU, wgrad_pipe_kernel): 320 divides Cout, the 256-column grid
         // wastes < 4 %, enough tiles, >= 10 q tiles (they share out the bias gradient's fragments) (PSG_WGRAD_PIPE=0: off)
@@ -1004,7 +1004,7 @@ static void wgrad_plan(const psg_wgrad_desc* d, WgP& p) {
         const int64_t tiles320 = (int64_t)(d->Cout / 320) * (q192 / 192);
         const int64_t ext = ((int64_t)p.M + 64) * d->lddy * 2;
         if (!off && d->dtype == PSG_BF16 && same && d->Cout % 320 == 0 && q192 * 100 <= (int64_t)p.Q * 104 && tiles320 >= mint && q192 / 192 >= 10 &&
-            ext < 0x7FFFFFF0ll) { p.wide = 3; p.BR = 320; BKP = 32; kSlots = 256; }
+            ext < 0x7FFFFFF0ll) { p.wide = 3; p.BR = 320; BKP = 32; kSlots = avail_cus(); }
     }
     p.rtiles = (d->Cout + p.BR - 1) / p.BR;
     p.qtiles = p.wide == 3 ? (p.Q + 191) / 192 : (p.wide ? (p.Q + 255) / 256 : (p.Q + 127) / 128);

@@ -1,4 +1,5 @@
-"""Which Python lines launch torch's own copy / add / cat kernels in a train step (torch.profiler, CPU+GPU, with_stack)."""
+"""Which Python lines launch torch's own copy / add / fill / cat work in a train step (torch.profiler, CPU+GPU, with_stack):
+every aten:: op that runs a kernel or a memcpy, grouped by (op, shapes, innermost package frames)."""
 import os, sys, collections, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import pokemon_sprite_generator_amd as psg
@@ -17,12 +18,13 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
     st.train_step(lat, txt, t)
     torch.cuda.synchronize()
 cnt = collections.Counter()
+LEAF = ("aten::copy_", "aten::add_", "aten::add", "aten::fill_", "aten::zero_", "aten::cat", "aten::mul_", "aten::mul", "aten::sqrt",
+        "aten::bitwise_and", "aten::bitwise_or", "aten::bitwise_or_", "aten::sum", "aten::normal_", "aten::random_", "aten::clamp")
 for e in prof.events():
-    ks = [k.name for k in (e.kernels or [])]
-    if not ks or not e.name.startswith("aten::"):
+    if e.name not in LEAF:
         continue
-    if any(("at::native" in k or "copyBuffer" in k) for k in ks):
-        stack = [f for f in (e.stack or []) if "pokemon_sprite_generator_amd" in f or "autograd" in f][:3]
-        cnt[(e.name, ks[0][:50], " <- ".join(s.split("/")[-1][:60] for s in stack))] += 1
-for (n, k, stk), c in sorted(cnt.items(), key=lambda kv: -kv[1])[:40]:
-    print(f"{c:4d} {n:18s} {k:52s} {stk}")
+    stack = [f for f in (e.stack or []) if "pokemon_sprite_generator_amd" in f or "tools/" in f][:3]
+    shapes = ""
+    cnt[(e.name, shapes, " <- ".join(s.split("/")[-1][:48] for s in stack))] += 1
+for (n, sh, stk), c in sorted(cnt.items(), key=lambda kv: -kv[1])[:50]:
+    print(f"{c:4d} {n:16s} {sh:42s} {stk}")
