@@ -251,6 +251,8 @@ def main():
                                                              "bucketed all-reduce (ncclAvg, async work handles on the side stream, "
                                                              "launched from the bucket-ready callbacks during backward) and the NaN-flag "
                                                              "MAX reduce really execute - the exchange is the identity, its cost is not")
+    ap.add_argument("--no-ddp-tune", action="store_true", help="data parallel: skip the start-up measurement that chooses between the overlapped "
+                                                               "(with / without a CU reserve) and the deferred gradient exchange")
     ap.add_argument("--no-secondary", action="store_true", help="skip the configs[1] / configs[4] legs of the default run")
     ap.add_argument("--dry-run", action="store_true", help="rendezvous check only: the ranks meet over gloo on the CPU, all-reduce a 1 "
                                                            "and rank 0 prints the world size (no GPU; tests/test_bench_cpu.py)")
@@ -296,6 +298,8 @@ def run_worker(args):
             torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
         else:
             backend = "nccl"                             # nccl == RCCL on ROCm
+            from pokemon_sprite_generator_amd import ddp as _ddp
+            _ddp.configure_rccl()                        # channel cap = the CU reserve the tile choosers plan around
             torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         probe = torch.ones(1, device=dev)
         torch.distributed.all_reduce(probe)              # a collective really ran: its sum IS the number of ranks
@@ -426,6 +430,8 @@ def run_worker(args):
     if sample_mode and graph and warmup < 2:
         warmup = 2                                       # step 0 is eager, step 1 captures
     one_step, prof_factory, run = make_steps(kind, B, graph)
+    if stepper.reducer is not None and kind != "sample" and not args.no_ddp_tune:
+        stepper.reducer.autotune(one_step, trials=2 if args.rehearse else 3)      # (untimed, before the warm-up: every rank takes part)
     elapsed, out = timed(one_step, steps, warmup)
     if sample_mode:
         loss, flag = None, int(not bool(torch.isfinite(run.x).all().item()))
@@ -506,6 +512,8 @@ def run_worker(args):
             res["allreduce_buckets"] = len(stepper.reducer.buckets)
             res["allreduce_buckets_launched_during_backward"] = stepper.reducer.launched_early
             res["allreduce_avg_in_collective"] = stepper.reducer.avg_in_collective
+            res["allreduce_mode"] = {"overlap": bool(stepper.reducer.overlap), "cu_reserve": stepper.reducer.cu_reserve,
+                                     "rccl_max_channels": os.environ.get("NCCL_MAX_NCHANNELS"), "tuned": stepper.reducer.tuned}
         if force_ddp:
             res["force_ddp"] = "process group of ONE rank over RCCL: every collective of the data-parallel step executes (identity exchange)"
         if args.rehearse:

@@ -144,6 +144,15 @@ def init(device_index: int):
     return lib
 
 
+AVAIL_CUS = [256]                        # mirror of psg_set_available_cus (ops caches split-K plans per value)
+
+
+def set_available_cus(device_index: int, n: int):
+    """psg_set_available_cus + the host-side mirror (n = 0: the whole chip)."""
+    check(init(device_index).psg_set_available_cus(int(n)), "psg_set_available_cus")
+    AVAIL_CUS[0] = 256 if n == 0 else int(n)
+
+
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
@@ -168,29 +177,83 @@ def ptr(t):
 
 
 # ---------------------------------------------------------------------------
-# grow-only device workspace (one per device; all kernels run on the current stream in order)
+# grow-only device workspace (one per (device, stream); all kernels on one stream run in order, so they share scratch)
 # ---------------------------------------------------------------------------
-_ws = {}
-_ws_frozen = False
+class WorkspacePool:
+    """key -> buffer, grown by replacement.  A captured hipGraph holds RAW POINTERS into the buffer of its capture stream, and
+    torch recycles stream handles (a pool of 32 per device), so the rules are:
+      * while frozen (a capture is open) a request that would replace a buffer raises - growth belongs to the eager warm-up;
+      * a graph owner `hold()`s the buffer its capture used: it keeps a reference (the memory cannot be freed under the
+        graph, whatever later happens to the key) and the key is marked held - a later, larger request on a recycled handle
+        then allocates a NEW buffer for the key and leaves the held one alone instead of freeing it;
+      * `drop()` (owner closed) releases the hold and, when the key's current buffer is the held one, the entry - so
+        repeated graph runs do not leave one buffer per recycled stream behind."""
+
+    def __init__(self, alloc):
+        self._alloc = alloc
+        self._bufs = {}
+        self._held = {}          # key -> list of buffers graph owners still point into
+        self.frozen = False
+
+    def get(self, key, nbytes, *alloc_args):
+        buf = self._bufs.get(key)
+        if buf is None or buf.numel() < nbytes:
+            if self.frozen:
+                raise PsgError(f"workspace of {nbytes} bytes requested inside a graph capture but the warm-up sized "
+                               f"{0 if buf is None else buf.numel()} on this stream: run the eager warm-up on the capture stream")
+            buf = self._alloc(max(int(nbytes), 1 << 20), *alloc_args)
+            self._bufs[key] = buf    # (a held predecessor stays alive through self._held and its owner)
+        return buf
+
+    def hold(self, key):
+        buf = self._bufs.get(key)
+        if buf is None:
+            raise PsgError("hold_workspace: no workspace was sized on this stream (run the eager warm-up first)")
+        self._held.setdefault(key, []).append(buf)
+        return key, buf
+
+    def drop(self, handle):
+        key, buf = handle
+        held = self._held.get(key, [])
+        for i, b in enumerate(held):
+            if b is buf:
+                del held[i]
+                break
+        if not held:
+            self._held.pop(key, None)
+            if self._bufs.get(key) is buf:
+                del self._bufs[key]
+
+    def __len__(self):
+        return len(self._bufs)
+
+
+_pool = WorkspacePool(lambda n, device: torch.empty(n, dtype=torch.uint8, device=device))
 
 
 def freeze_workspaces(on: bool):
     """While frozen (a hipGraph capture is open) a request that would REPLACE a workspace raises: kernels already captured
     keep pointing at the old buffer, so growth must have happened in the eager warm-up on the same stream."""
-    global _ws_frozen
-    _ws_frozen = bool(on)
+    _pool.frozen = bool(on)
+
+
+def _ws_key(device):
+    di = device.index if device.index is not None else torch.cuda.current_device()
+    return (di, _raw_stream(di) if _raw_stream is not None else torch.cuda.current_stream(device).cuda_stream)
 
 
 def workspace(nbytes: int, device):
     # one buffer per (device, stream): kernels on one stream run in order, so they can share scratch; a second
     # stream (ops: weight gradients overlapped with data gradients) gets its own
-    di = device.index if device.index is not None else torch.cuda.current_device()
-    key = (di, _raw_stream(di) if _raw_stream is not None else torch.cuda.current_stream(device).cuda_stream)
-    buf = _ws.get(key)
-    if buf is None or buf.numel() < nbytes:
-        if _ws_frozen:
-            raise PsgError(f"workspace of {nbytes} bytes requested inside a graph capture but the warm-up sized "
-                           f"{0 if buf is None else buf.numel()} on this stream: run the eager warm-up on the capture stream")
-        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
-        _ws[key] = buf
-    return buf
+    return _pool.get(_ws_key(device), nbytes, device)
+
+
+def hold_workspace(device):
+    """For the owner of a captured graph, called on the capture stream after the capture: pins the buffer the captured launches
+    point into (see WorkspacePool).  Returns a handle for `drop_workspace`."""
+    return _pool.hold(_ws_key(device))
+
+
+def drop_workspace(handle):
+    if handle is not None:
+        _pool.drop(handle)

@@ -75,12 +75,13 @@ static ConvPlan conv_plan(const ConvP& p, int dtype, bool may_split) {
 
 static int choose_and_launch(const ConvP& p0, int dtype, hipStream_t s) {
     ConvP p = p0;
-    const ConvPlan pl = conv_plan(p, dtype, p.ws != nullptr);
-    const int BM = pl.BM, BN = pl.BN;
+    ConvPlan pl = conv_plan(p, dtype, p.ws != nullptr);
     p.splits = 1; p.kt_per_split = p.KT;
-    if (pl.splits > 1 && p.ws != nullptr && (int64_t)pl.splits * p.M * p.N * 4 <= p.ws_bytes) {
-        p.splits = pl.splits; p.kt_per_split = pl.kt_per_split;
+    if (pl.splits > 1) {
+        if (p.ws != nullptr && (int64_t)pl.splits * p.M * p.N * 4 <= p.ws_bytes) { p.splits = pl.splits; p.kt_per_split = pl.kt_per_split; }
+        else pl = conv_plan(p, dtype, false);          // workspace too small: the best UNSPLIT tile, not the split plan's tile
     }
+    const int BM = pl.BM, BN = pl.BN;
 #ifdef PSG_ABL
     if (PSG_ABL & 8) { const char* e = getenv("PSG_DBG_PTR"); p.ws = (e && p.splits <= 1) ? reinterpret_cast<float*>(strtoull(e, nullptr, 0)) : (p.splits <= 1 ? nullptr : p.ws); }
 #endif

@@ -993,7 +993,7 @@ static void wgrad_plan(const psg_wgrad_desc* d, WgP& p) {
     }
     int kSlots = 2 * avail_cus();
     {
-        // pipelined 320 x 256 tiles (one 256-thread workgroup per CU, wgrad_pipe_kernel): 320 divides Cout, the 256-column grid
+        // pipelined 320 x 192 tiles (one 256-thread workgroup per CU, wgrad_pipe_kernel): 320 divides Cout, the 192-column grid
         // wastes < 4 %, enough tiles, >= 10 q tiles (they share out the bias gradient's fragments) (PSG_WGRAD_PIPE=0: off)
         static int off = -1;
         if (off < 0) { const char* e = getenv("PSG_WGRAD_PIPE"); off = (e && atoi(e) == 0) ? 1 : 0; }

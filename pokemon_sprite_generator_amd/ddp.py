@@ -13,8 +13,27 @@ rounded to bf16 into a staging buffer, summed by RCCL in bf16 and widened back i
 strong-scaling corner (per-GPU batch <= 32) where a single ring's 29 ms would not hide behind backward
 (SURVEY.md §8e); at per-GPU batch 256 the fp32 exchange hides completely and stays the default.
 """
+import os
+import time
+
 import torch
 import torch.distributed as dist
+
+# CUs the tile choosers leave to an overlapped all-reduce (DESIGN.md §7, tools/contention.py): a launch planned as ONE round of
+# workgroups over 256 CUs takes two rounds as soon as a collective's channels sit on a few of them (batch-256 step on a
+# CU-masked stream: 240 CUs +26 %, 224 CUs +28 % with plans made for 256; +11 % at 224 with plans made for 224).  The
+# dispatcher deals workgroups round-robin over 8 XCDs x 4 shader engines, so the reserve is a whole CU per engine (32), and
+# RCCL is capped at that many channels (`configure_rccl`, before init_process_group).
+CU_RESERVE = int(os.environ.get("PSG_DDP_CU_RESERVE", "32"))
+
+
+def configure_rccl(max_channels=None):
+    """Cap the channels (= resident workgroups, one CU each) RCCL may use at the CU reserve the tile choosers plan for.
+    Call BEFORE torch.distributed.init_process_group; an explicit NCCL_MAX_NCHANNELS in the environment wins."""
+    n = CU_RESERVE if max_channels is None else int(max_channels)
+    if n > 0:
+        os.environ.setdefault("NCCL_MAX_NCHANNELS", str(n))
+    return int(os.environ.get("NCCL_MAX_NCHANNELS", "0") or 0)
 
 
 def dist_info():
@@ -29,7 +48,8 @@ def rank_generator(device, rank=None, world=None):
     eps), or None (= torch's default generator) in a single process.  The reference's loaders seed every process alike
     (dataset_improved.py:254), which the loader shuffle NEEDS (ddp.ShardedLoader) - but the same seed on every device
     generator would hand all N shards of a global batch identical t / noise / eps: B/N distinct draws instead of B.
-    Seed: torch.initial_seed() + rank (the CPU generator stays shared, so shuffles still agree)."""
+    Seed: torch.initial_seed() mixed with the rank by a golden-ratio multiply (distinct, well-separated streams; the CPU
+    generator stays shared, so shuffles still agree)."""
     if rank is None or world is None:
         rank, world = dist_info()
     if world <= 1:
@@ -128,8 +148,11 @@ class BucketedAllReduce:
     box: `DiffusionStepper(distributed="force")`, `bench.py --gpus 1 --force-ddp`, tests/test_ddp_gpu.py."""
 
     def __init__(self, arena_flat, params, offsets, bucket_bytes=64 << 20, process_group=None, overlap=True,
-                 bucket_dtype=torch.float32, force_single=False):
+                 bucket_dtype=torch.float32, force_single=False, cu_reserve=None):
         self.flat = arena_flat
+        self.cu_reserve = CU_RESERVE if cu_reserve is None else int(cu_reserve)
+        self._cus_set = False
+        self.tuned = None                  # autotune()'s record
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (bool(force_single) and dist.is_initialized())
@@ -183,6 +206,41 @@ class BucketedAllReduce:
         dist.all_reduce(agree, op=dist.ReduceOp.MIN, group=group)
         return bool(int(agree.item()))
 
+    def autotune(self, run_step, trials=3):
+        """Choose HOW the exchange runs on this machine by measuring it (the answer depends on how many CUs RCCL's channels
+        take and on the links - unknowable on a 1-GPU box): `run_step()` executes one full train step; three settings are
+        timed, `trials` steps each after one untimed step: buckets overlapped with backward and tiles planned around the CU
+        reserve ("overlap+reserve"), overlapped with plans for the whole chip ("overlap"), and the whole exchange after backward
+        ("deferred": no contention, nothing hidden).  Ranks agree through a MAX all-reduce of the times (the job runs at the
+        pace of its slowest rank) and all take the same fastest setting.  Returns the record (also kept in `.tuned`)."""
+        if not self.active:
+            return None
+        settings = [("overlap+reserve", True, self.cu_reserve), ("overlap", True, 0), ("deferred", False, 0)]
+        if self.cu_reserve <= 0 or self._stream is None:
+            settings = [x for x in settings if x[0] != "overlap+reserve"]
+        if self._stream is None:
+            settings = [x for x in settings if x[1] is False]
+        times = []
+        for name, ov, res in settings:
+            self.overlap, self.cu_reserve = ov and self._stream is not None, res
+            run_step()
+            if self.flat.is_cuda:
+                torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(trials):
+                run_step()
+            if self.flat.is_cuda:
+                torch.cuda.synchronize()
+            times.append((time.perf_counter() - t0) / trials)
+        tt = torch.tensor(times, dtype=torch.float64, device=self.flat.device if dist.get_backend(self.group) == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=self.group)
+        tl = [float(x) for x in tt.tolist()]
+        best = min(range(len(tl)), key=lambda i: tl[i])
+        name, ov, res = settings[best]
+        self.overlap, self.cu_reserve = ov and self._stream is not None, res
+        self.tuned = {"chosen": name, "ms_per_step": {settings[i][0]: 1e3 * tl[i] for i in range(len(tl))}, "trials": trials}
+        return self.tuned
+
     def reset(self):
         """Back to 'no gradient seen' (start of a step; also the recovery point after a failed step: pending counters and
         outstanding work handles of a half-finished exchange are dropped)."""
@@ -209,8 +267,20 @@ class BucketedAllReduce:
         st.copy_(view)                                             # fp32 -> bf16 (round to nearest even)
         return dist.all_reduce(st, op=self.op, group=self.group, async_op=True), (view, st)
 
+    def _plan_cus(self, reserve):
+        """Tell the tile choosers how many CUs they have while buckets are in flight (host-side planning input; the host runs
+        ahead of the GPU by a few launches, so the window is approximate - a plan for 224 CUs on 256 free ones costs ~1 %)."""
+        if not self.flat.is_cuda:
+            return
+        from . import _lib
+        _lib.set_available_cus(self.flat.device.index if self.flat.device.index is not None else torch.cuda.current_device(),
+                               0 if reserve <= 0 else 256 - int(reserve))
+        self._cus_set = reserve > 0
+
     def _launch(self, b):
         s, e, _ = self.buckets[b]
+        if self.overlap and self.cu_reserve > 0 and not self._cus_set and self._stream is not None:
+            self._plan_cus(self.cu_reserve)          # first bucket of the step leaves during backward: plan around it from here on
         if self._stream is not None:
             self._stream.wait_stream(torch.cuda.current_stream())
             from .ops import SideStream            # weight gradients are produced on the side stream
@@ -243,6 +313,8 @@ class BucketedAllReduce:
                 back[0].copy_(back[1])
         if self._stream is not None:
             torch.cuda.current_stream().wait_stream(self._stream)
+        if self._cus_set:
+            self._plan_cus(0)                        # exchange over: the whole chip again (clip, AdamW, next forward)
         if not self.avg_in_collective:
             self.flat.mul_(1.0 / self.world)
         early = self._early

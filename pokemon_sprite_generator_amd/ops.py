@@ -269,6 +269,12 @@ class SplitKStats:
     launches = 0
 
 
+# psg_conv_fwd_workspace_bytes validates the descriptor and evaluates the tile / split plan: per (geometry, dtype, CUs the
+# planner counts on) that answer never changes, and on the launch-bound small-batch / sampler paths the second host call
+# per launch was as long as the launch itself
+_splitk_need = {}
+
+
 def _conv_launch(lib, dtype, x, ldx, w, ldw, y, ldy, geom, Cin, Cout, transposed=False, bias=None, rowadd=None,
                  residual=None, ld_res=0, preact=None, dact_u=None, ld_dact=0, act=ACT_NONE, alpha=1.0, drop_p=0.0, seed=0, flags=0):
     B, Hi, Wi, Ho, Wo, ks, stride, pad = geom
@@ -284,7 +290,10 @@ def _conv_launch(lib, dtype, x, ldx, w, ldw, y, ldy, geom, Cin, Cout, transposed
     # small grids (sampling, small batches): offer a split-K workspace.  Only launches with few output elements are asked
     # about (one plan evaluation on the host); a batch-256 train step never is.
     if B * Ho * Wo * Cout <= _SPLITK_MAX_OUT and _SPLITK:
-        need = lib.psg_conv_fwd_workspace_bytes(cp)
+        key = (dtype, geom, Cin, Cout, transposed, _lib.AVAIL_CUS[0])
+        need = _splitk_need.get(key)
+        if need is None:
+            need = _splitk_need[key] = lib.psg_conv_fwd_workspace_bytes(cp)
         if need > 0:
             ws = _lib.workspace(need, x.device)
             struct.pack_into("<Qq", cb, _CONV_FMT.size - 16, ws.data_ptr(), ws.numel())
@@ -408,6 +417,7 @@ class SeedSource:
     fixed from step to step (unet._SeedStream restarts its counter each step) and this word, advanced ON THE DEVICE at the end
     of every step, is what changes - eager steps and graph replays then draw identical masks."""
     _t = None
+    _users = 0                              # acquire / release count (one per captured train-step graph)
     _STEP = -7046029254386353131            # 0x9E3779B97F4A7C15 as int64 (wraps)
 
     @classmethod
@@ -423,10 +433,25 @@ class SeedSource:
         return cls._t
 
     @classmethod
+    def acquire(cls, device):
+        """One count per captured graph: the device word is baked into the captured launches' arguments and must stay alive
+        (and keep advancing) until the LAST graph that reads it is closed."""
+        cls._users += 1
+        return cls.enable(device)
+
+    @classmethod
+    def release(cls):
+        if cls._users > 0:
+            cls._users -= 1
+            if cls._users == 0:
+                cls.disable()
+
+    @classmethod
     def disable(cls):
         if cls._t is not None:
             check(_lib.load().psg_set_seed_source(None), "psg_set_seed_source")
             cls._t = None
+        cls._users = 0
 
     @classmethod
     def advance(cls):

@@ -60,7 +60,7 @@ class DiffusionStepper:
 
     def __init__(self, unet: UNet, noise_scheduler: NoiseScheduler, lr=1e-4, betas=(0.9, 0.999), weight_decay=0.01,
                  eps=1e-6, max_grad_norm=1.0, optimizer_type="adamw", distributed=None, bucket_bytes=64 << 20,
-                 grad_bucket_dtype=torch.float32):
+                 grad_bucket_dtype=torch.float32, ddp_cu_reserve=None):
         self.unet, self.noise_scheduler = unet, noise_scheduler
         self.max_grad_norm = max_grad_norm
         self.device = next(unet.parameters()).device
@@ -89,22 +89,22 @@ class DiffusionStepper:
         else:
             self.optimizer = torch.optim.Adam(self.arena.params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self.reducer = BucketedAllReduce(self.arena.flat, self.arena.params, self.arena.offsets, bucket_bytes,
-                                         bucket_dtype=grad_bucket_dtype, force_single=force_single) if distributed else None
+                                         bucket_dtype=grad_bucket_dtype, force_single=force_single,
+                                         cu_reserve=ddp_cu_reserve) if distributed else None
         self.flag = torch.zeros(1, dtype=torch.int32, device=self.device)      # bits: enum psg_flag (include/psg_hip.h)
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.criterion_beta = 0.1                                               # nn.SmoothL1Loss(beta=0.1) :300
         self.host_steps = 0                                                     # (torch.optim.Adam branch only)
         # data parallel: this rank's own stream for t / noise / VAE eps (None = torch's default generator); see ddp.rank_generator
         self.generator = rank_generator(self.device) if distributed else None
-        self._seed_source_owner = False
+        self._graphs = []                          # live GraphedTrainStep objects of this stepper (closed with it)
 
     def close(self):
         """Release the process-wide registrations (gradient sinks, bf16 shadow, the graph-replay seed word) of this stepper."""
+        for g in list(self._graphs):               # (each holds one count of the seed source and its capture stream's workspace)
+            g.close()
         self.arena.release()
         self.params.release()
-        if self._seed_source_owner:                # (capture_train_step switched the dropout seeds to the device word)
-            ops_mod.SeedSource.disable()
-            self._seed_source_owner = False
 
     def randn_like(self, x):
         """randn_like from this rank's stream (:373)."""
@@ -187,7 +187,8 @@ class DiffusionStepper:
         all-reduce inside the graph).  23 ms of launches per step become one replay: the step is GPU-bound at any batch.
         MODE SWITCH: capturing enables `ops.SeedSource` (fixed per-site dropout seeds + a device word advanced every step)
         for the whole process - eager steps of this and any other stepper draw their masks that way too from then on -
-        until this stepper's `close()` (or `ops.SeedSource.disable()`) switches it back."""
+        until the LAST live graph is closed (`GraphedTrainStep.close()`, or this stepper's `close()`; the source is reference
+        counted, one count per graph: the device word is baked into captured kernel arguments)."""
         if self.reducer is not None:
             raise NotImplementedError("capture_train_step: data-parallel steps are not captured")
         if not isinstance(self.optimizer, FusedAdamW):
@@ -244,9 +245,9 @@ class GraphedTrainStep:
         from .ops import SeedSource, WeightCache
         self.stepper = stepper
         dev = stepper.device
-        if not SeedSource.enabled():
-            stepper._seed_source_owner = True
-        SeedSource.enable(dev)
+        SeedSource.acquire(dev)
+        self._ws_hold = None
+        self._closed = False
         self.lat, self.txt, self.t = latents.detach().clone(), text_emb.detach().clone(), t.detach().clone()
         # Warm-up AND capture run on ONE stream of ours: the scratch workspace is keyed by (device, stream), so the eager
         # steps size exactly the buffers the captured launches will use and nothing is (re)allocated inside the capture.
@@ -263,11 +264,30 @@ class GraphedTrainStep:
                     self.out = stepper.train_step(self.lat, self.txt, self.t)
             finally:
                 _lib.freeze_workspaces(False)
+            # the captured launches hold raw pointers into this stream's scratch buffer: pin it (torch recycles stream handles)
+            self._ws_hold = _lib.hold_workspace(dev)
+        self._stream = side
         torch.cuda.current_stream(dev).wait_stream(side)
         WeightCache.invalidate()
+        stepper._graphs.append(self)
+
+    def close(self):
+        """Release what the graph pinned: its capture stream's workspace and one count of the dropout seed source."""
+        if self._closed:
+            return
+        self._closed = True
+        from .ops import SeedSource
+        self.graph = None
+        _lib.drop_workspace(self._ws_hold)
+        self._ws_hold = None
+        SeedSource.release()
+        if self in self.stepper._graphs:
+            self.stepper._graphs.remove(self)
 
     def run(self, latents=None, text_emb=None, t=None):
         from .ops import WeightCache
+        if self._closed:
+            raise _lib.PsgError("GraphedTrainStep.run after close()")
         if latents is not None:
             self.lat.copy_(latents)
         if text_emb is not None:
@@ -319,6 +339,20 @@ class SamplerRun:
         # by (device, stream), so step 0 sizes exactly the buffers the captured launches use (nothing is allocated or
         # replaced inside the capture: _lib.freeze_workspaces enforces it)
         self._stream = torch.cuda.Stream(device=dev) if self.use_graph else None
+        self._ws_hold = None
+
+    def close(self):
+        """Drop the graph and the scratch buffer it pinned (also runs when the chain completes and on garbage collection)."""
+        self.graph = None
+        if self._ws_hold is not None:
+            _lib.drop_workspace(self._ws_hold)
+            self._ws_hold = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                            # noqa: BLE001 - interpreter shutdown
+            pass
 
     def remaining(self):
         return len(self.order) - self.i
@@ -344,6 +378,8 @@ class SamplerRun:
                 self._graph_step()
             cur.wait_stream(self._stream)
         self.i += 1
+        if self.i >= len(self.order):
+            self.close()
         return self.x
 
     def _graph_step(self):
@@ -360,6 +396,7 @@ class SamplerRun:
                     _lib.freeze_workspaces(False)
                 self.x.copy_(x_before)                  # capture does not execute: the replay below runs this step
                 self.graph = graph
+                self._ws_hold = _lib.hold_workspace(self.st.device)     # (we are on the capture stream: its scratch is now pinned)
             except Exception as e:                      # noqa: BLE001
                 logging.getLogger(__name__).warning(f"hipGraph capture of the sampler step failed ({e!r}); running eagerly")
                 self.use_graph = False
@@ -612,8 +649,14 @@ class ImprovedDiffusionTrainer:
             gen = self.stepper.generator
             from .vae import VAEEncoder as _OwnEncoder
             if gen is not None and isinstance(self.vae_encoder, _OwnEncoder):      # this rank's own reparameterisation noise
-                eps = torch.randn((images.shape[0], self.vae_encoder.latent_dim, 27, 27), device=self.device, generator=gen)
-                latent = self.vae_encoder(images, eps)
+                latent = self.vae_encoder(images, generator=gen)                   # (drawn with mu's shape, whatever the image size)
+            elif gen is not None and images.is_cuda:
+                # an injected / reference encoder draws with randn_like from the DEFAULT generator, seeded alike on every
+                # rank: fork it for the call and seed the fork from this rank's stream (one host read per batch, foreign
+                # encoders under data parallel only)
+                with torch.random.fork_rng(devices=[images.device]):
+                    torch.cuda.manual_seed(int(torch.randint(0, 2 ** 62, (1,), device=self.device, generator=gen).item()))
+                    latent = self.vae_encoder(images)
             else:
                 latent = self.vae_encoder(images)
             latent = latent[0] if isinstance(latent, (tuple, list)) else latent

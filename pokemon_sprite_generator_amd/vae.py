@@ -155,9 +155,10 @@ class VAEEncoder(nn.Module):
         self._cache = {}
 
     @torch.no_grad()
-    def forward(self, x: torch.Tensor, eps: torch.Tensor = None):
-        """x [B,3,215,215] -> (latent, mu, logvar), each [B,latent_dim,27,27] fp32.  `eps` (default randn) is the
-        reparameterisation noise the reference draws with randn_like (:121)."""
+    def forward(self, x: torch.Tensor, eps: torch.Tensor = None, generator: torch.Generator = None):
+        """x [B,3,H,W] -> (latent, mu, logvar), each [B,latent_dim,h,w] fp32 (215 -> 27).  `eps` (default: randn of mu's
+        shape, from `generator` when given - a data-parallel rank's own stream) is the reparameterisation noise the
+        reference draws with randn_like (:121)."""
         if not x.is_cuda:
             raise _lib.PsgError("VAEEncoder (MI355X build) needs GPU tensors; there is no CPU fallback")
         dt = self.compute_dtype
@@ -181,7 +182,7 @@ class VAEEncoder(nn.Module):
         mu = ops.nhwc_to_nchw(_conv(h, wm, self.mu_proj.bias, 512, self.latent_dim, 3, 1, 1))
         logvar = ops.nhwc_to_nchw(_conv(h, wl, self.logvar_proj.bias, 512, self.latent_dim, 3, 1, 1))
         if eps is None:
-            eps = torch.randn_like(mu)
+            eps = torch.randn_like(mu) if generator is None else torch.randn(mu.shape, dtype=mu.dtype, device=mu.device, generator=generator)
         eps = eps.to(device=mu.device, dtype=torch.float32).contiguous()
         latent = torch.empty_like(mu)
         check(lib.psg_reparam_f32(ptr(mu), ptr(logvar), ptr(eps), ptr(latent), mu.numel(), stream_ptr()), "psg_reparam_f32")

@@ -113,3 +113,50 @@ def test_inline_asm_mfmas_have_no_valu_write_hazard(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mfma_hazard_check.py"), asm, "wgrad_pipe_kernel"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
     assert " 0 hazards" in r.stdout and not r.stdout.startswith("0 MFMAs"), r.stdout
+
+
+def test_workspace_pool_never_frees_a_buffer_a_graph_holds():
+    """a captured hipGraph points into the scratch buffer of its capture stream, and torch recycles stream handles.
+    The pool's rules (pokemon_sprite_generator_amd/_lib.py::WorkspacePool), on a fake allocator: a held buffer survives a later,
+    larger request on the same key (the key gets a NEW buffer); growth inside a capture raises; drop() releases the entry."""
+    from pokemon_sprite_generator_amd._lib import PsgError, WorkspacePool
+
+    class Buf:
+        live = 0
+
+        def __init__(self, n):
+            self.n = n
+            Buf.live += 1
+
+        def numel(self):
+            return self.n
+
+        def __del__(self):
+            Buf.live -= 1
+
+    pool = WorkspacePool(lambda n: Buf(n))
+    key = (0, 1234)
+    a = pool.get(key, 10)
+    assert pool.get(key, 5) is a and a.numel() == 1 << 20          # grow-only, 1 MiB floor
+    handle = pool.hold(key)                                        # a graph captured on this stream points into `a`
+    pool.frozen = True
+    with pytest.raises(PsgError):
+        pool.get(key, 2 << 20)                                     # growth inside a capture
+    pool.frozen = False
+    b = pool.get(key, 2 << 20)                                     # a recycled stream handle, a larger eager request
+    assert b is not a and handle[1] is a
+    del a
+    import gc
+    gc.collect()
+    assert Buf.live == 2                                           # the held buffer is still alive (the graph can replay)
+    pool.drop(handle)
+    del handle
+    gc.collect()
+    assert Buf.live == 1 and len(pool) == 1                        # only the current buffer remains
+    h2 = pool.hold(key)
+    pool.drop(h2)                                                  # owner of the CURRENT buffer closed: the entry goes too
+    del h2, b
+    gc.collect()
+    assert len(pool) == 0 and Buf.live == 0
+    with pytest.raises(PsgError):
+        pool.hold((0, 99))                                         # nothing was sized on that stream

@@ -44,6 +44,18 @@ def _worker(rank, world, port, bucket_bytes, q, bucket_dtype="fp32"):
             for i, p in enumerate(params):
                 want = sum((r + 1) * (i + 1) + step for r in range(world)) / world
                 assert torch.allclose(p.grad, torch.full(p.shape, want)), (rank, i, step)
+        # the start-up measurement that picks the exchange mode: ranks must leave it with the SAME choice (MAX all-reduce of the
+        # times).  On CPU tensors there is no side stream, so "deferred" is the only candidate - the agreement path still runs.
+        calls = []
+
+        def one_step():
+            calls.append(1)
+            for i, p in enumerate(params):
+                p.grad.copy_(torch.full(p.shape, float(rank + i)))
+            red.finish()
+        tuned = red.autotune(one_step, trials=2)
+        assert tuned["chosen"] == "deferred" and list(tuned["ms_per_step"]) == ["deferred"] and len(calls) == 3, tuned
+        assert red.overlap is False and red.tuned is tuned
         q.put((rank, len(red.buckets), "ok"))
     except Exception as e:  # noqa: BLE001
         q.put((rank, -1, repr(e)))

@@ -26,7 +26,7 @@ for ncu in (256, 240, 224, 192):
     _lib.check(lib.psg_stream_create_cu_mask(ncu, C.byref(sp)), "psg_stream_create_cu_mask")
     ext = torch.cuda.ExternalStream(sp.value, device=dev)
     for plan in (("blind", 256), ("matched", ncu)) if ncu != 256 else (("blind", 256),):
-        _lib.check(lib.psg_set_available_cus(plan[1]), "psg_set_available_cus")
+        _lib.set_available_cus(0, 0 if plan[1] == 256 else plan[1])
         ext.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(ext):
             for _ in range(2):
@@ -50,7 +50,7 @@ for ncu in (256, 240, 224, 192):
         print(json.dumps(row), flush=True)
     torch.cuda.current_stream(dev).wait_stream(ext)
     torch.cuda.synchronize()
-    _lib.check(lib.psg_set_available_cus(0), "psg_set_available_cus")
+    _lib.set_available_cus(0, 0)
     del ext
     _lib.check(lib.psg_stream_destroy(sp), "psg_stream_destroy")
 base = rows[0]["ms_per_step"]
