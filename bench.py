@@ -34,6 +34,14 @@ sys.path.insert(0, ROOT)
 # projections from the counter; the arithmetic is the same in both modes.
 FWD_GFLOP_PER_SAMPLE = 77.46
 FWD_BWD_GFLOP_PER_SAMPLE = 232.12
+# Both constants come from ONE method - FlopCounterMode over the reference module with autograd recording (train or eval mode
+# alike: 77.464 forward, 232.120 forward + SmoothL1 + backward; re-counted in round 4).  70.83 is what the same counter sees
+# under no_grad, where nn.MultiheadAttention takes its fused fast path and the projections disappear from the count.
+FLOP_MODEL = {"method": "torch.utils.flop_counter.FlopCounterMode on the reference U-Net, 2*MAC, autograd recording",
+              "fwd_gflop_per_sample": 77.464, "fwd_bwd_gflop_per_sample": 232.120,
+              "fwd_gflop_per_sample_no_grad_fastpath": 70.83,
+              "note": "70.83 (SURVEY.md 8d as first written) hides the MHA projections behind torch's fused eval path; the fwd+bwd "
+                      "figure was always the autograd-mode count, so step fractions of rounds 1-4 are comparable"}
 PEAK_BF16 = 2.5e15                      # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_F32 = 157.3e12                     # fp32 matrix (= vector) rate
 KINDS = ["conv_gemm(fwd gather)", "conv_gemm(dgrad gather)", "wgrad", "attention", "groupnorm"]
@@ -313,7 +321,7 @@ def run_worker(args):
     dtype_name = args.dtype or ("fp32" if fwd_bwd_only else "bf16")
     dtype = torch.bfloat16 if dtype_name == "bf16" else torch.float32
     B = args.batch or (8 if args.rehearse else (64 if (sample_mode or fwd_bwd_only) else 256))
-    steps = args.steps if args.steps is not None else (2 if args.rehearse else (50 if sample_mode else 10))
+    steps = args.steps if args.steps is not None else (2 if args.rehearse else (50 if sample_mode else 20))
     warmup = args.warmup if args.warmup is not None else (1 if args.rehearse else (5 if sample_mode else 3))
     torch.manual_seed(1234)                      # (replicas are made equal by the stepper's rank-0 broadcast, not by this)
     unet = psg.UNet(latent_dim=8, text_dim=256, time_emb_dim=128, num_heads=8, compute_dtype=dtype).to(dev)
@@ -365,16 +373,26 @@ def run_worker(args):
             return stepper.train_step(latents, text, t, noise)
         return one_step, (lambda: one_step), None
 
-    def timed(one_step, nsteps, nwarm):
+    step_stats = {}
+
+    def timed(one_step, nsteps, nwarm, tag="main"):
+        """Wall clock over exactly `nsteps` steps between two barriers (the contract's figure) + one HIP event between
+        consecutive steps on the launch stream: per-step device times, reported as median / min."""
         out = None
         for _ in range(nwarm):
             out = one_step()
         barrier()
+        evs = [torch.cuda.Event(enable_timing=True) for _ in range(nsteps + 1)]
         t0 = time.perf_counter()
-        for _ in range(nsteps):
+        for i in range(nsteps):
+            evs[i].record()
             out = one_step()
+        evs[nsteps].record()
         barrier()
         el = time.perf_counter() - t0
+        per = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(nsteps))
+        step_stats[tag] = {"median": per[len(per) // 2] if len(per) % 2 else 0.5 * (per[len(per) // 2 - 1] + per[len(per) // 2]),
+                           "min": per[0], "max": per[-1], "n": nsteps, "how": "HIP events between consecutive steps on the launch stream"}
         tmax = torch.tensor([el], device=dev, dtype=torch.float64)
         if world > 1 or force_ddp:
             torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
@@ -397,8 +415,9 @@ def run_worker(args):
         fam = None
         if rank == 0:
             n = len(KINDS)
-            ms, work, cnt = (C.c_double * n)(), (C.c_double * n)(), (C.c_int64 * n)()
+            ms, work, cnt, byt = (C.c_double * n)(), (C.c_double * n)(), (C.c_int64 * n)(), (C.c_double * n)()
             _lib.check(lib.psg_profile_end(ms, work, cnt, n), "psg_profile_end")
+            _lib.check(lib.psg_profile_bytes(byt, n), "psg_profile_bytes")
             fam = []
             for i, name in enumerate(KINDS):
                 if cnt[i] == 0:
@@ -408,7 +427,8 @@ def run_worker(args):
                 fam.append({"kernel": name, "launches_per_step": cnt[i] / nsteps, "ms_per_step": ms[i] / nsteps,
                             "avg_launch_us": 1e3 * ms[i] / cnt[i], "bound": "hbm" if is_bytes else "mfma",
                             "achieved": ach / (1e9 if is_bytes else 1e12), "unit": "GB/s" if is_bytes else "TFLOP/s",
-                            "peak": 8000.0 if is_bytes else peak / 1e12, "frac": ach / (8e12 if is_bytes else peak)})
+                            "peak": 8000.0 if is_bytes else peak / 1e12, "frac": ach / (8e12 if is_bytes else peak),
+                            "algorithmic_bytes_per_launch": byt[i] / cnt[i]})
         ops.SideStream.enabled = overlap
         return fam
 
@@ -418,7 +438,9 @@ def run_worker(args):
         # read from inside the process): attached only when a committed summary matches this build AND workload
         traffic, traffic_src = _traffic_for(build_id, dom["kernel"], workload_key)
         return {"bound": dom["bound"], "achieved": dom["achieved"], "peak": dom["peak"], "unit": dom["unit"],
-                "frac": dom["frac"], "traffic": traffic, "traffic_unit": "bytes/launch (memory-side requests incl. Infinity-Cache hits)",
+                "frac": dom["frac"], "traffic": traffic, "algorithmic_bytes": dom.get("algorithmic_bytes_per_launch"),
+                "traffic_ratio": (traffic / dom["algorithmic_bytes_per_launch"]) if (traffic and dom.get("algorithmic_bytes_per_launch")) else None,
+                "traffic_unit": "bytes/launch (memory-side requests incl. Infinity-Cache hits)",
                 "traffic_source": traffic_src, "kernel": dom["kernel"],
                 "avg_launch_us": dom["avg_launch_us"], "launches_per_step": dom["launches_per_step"],
                 "ms_per_step": dom["ms_per_step"],
@@ -448,12 +470,13 @@ def run_worker(args):
         # configs[1]: forward + SmoothL1 + backward, exact-fp32 MFMA, batch 64
         unet.set_compute_dtype(torch.float32)
         s1, p1, _ = make_steps("fwd_bwd", 64)
-        el1, o1 = timed(s1, 5, 2)
+        el1, o1 = timed(s1, 5, 2, "fwd_bwd_fp32_bs64")
         f1 = families(p1, 1, PEAK_F32) if not args.no_profile else None
         sps1 = 5 * 64 / el1
         secondary["fwd_bwd_fp32_bs64"] = {
             "metric": "unet_fwd_bwd_steps_per_sec_bs64", "value": 5 / el1, "unit": "bs64-steps/s", "steps": 5, "warmup": 2,
             "ms_per_step": 1e3 * el1 / 5, "dtype": "fp32", "samples_per_s": sps1,
+            "step_ms": step_stats.get("fwd_bwd_fp32_bs64"),
             "step_mfma_frac_of_peak": sps1 * FWD_BWD_GFLOP_PER_SAMPLE * 1e9 / PEAK_F32, "final_loss": float(o1["loss"].item()),
             "config": {"workload": "BASELINE configs[1]: add_noise + U-Net forward + SmoothL1 + backward (no optimizer), batch 64, "
                                    "fp32 (exact fp32 MFMA), train mode (dropout 0.05)"}}
@@ -462,11 +485,12 @@ def run_worker(args):
         unet.set_compute_dtype(torch.bfloat16)
         # configs[4] per GPU: denoising steps of the 1000-step DDPM loop, 64 samples, hipGraph replay
         s4, p4, run4 = make_steps("sample", 64, True)
-        el4, _ = timed(s4, 30, 3)
+        el4, _ = timed(s4, 30, 3, "sample_bf16_n64")
         f4 = families(p4, 3, PEAK_BF16) if not args.no_profile else None
         secondary["sample_bf16_n64"] = {
             "metric": "ddpm_denoise_steps_per_sec_n64", "value": 30 / el4, "unit": "denoise-steps/s (64 samples per GPU each)",
             "steps": 30, "warmup": 3, "ms_per_step": 1e3 * el4 / 30, "dtype": "bf16", "samples_per_s": 30 * 64 / el4,
+            "step_ms": step_stats.get("sample_bf16_n64"),
             "step_mfma_frac_of_peak": (30 * 64 / el4) * FWD_GFLOP_PER_SAMPLE * 1e9 / PEAK_BF16,
             "finite": bool(torch.isfinite(run4.x).all().item()),
             "config": {"workload": "BASELINE configs[4] per GPU: DDPM sampling loop (ddpm_sample :508-569), 1000-step schedule, 64 samples, "
@@ -502,7 +526,7 @@ def run_worker(args):
             "n_gpus": world, "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
             "config": {"workload": workload, "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}"},
-            "samples_per_s": samples_per_s,
+            "samples_per_s": samples_per_s, "step_ms": step_stats.get("main"), "flop_model": FLOP_MODEL,
             "step_mfma_frac_of_peak": samples_per_s * gflop * 1e9 / (peak * world),
             "final_loss": loss, "nan_flag": flag, "build_id": build_id,
             "nccl_world_size": nccl_world, "collective_backend": backend,

@@ -354,6 +354,9 @@ int psg_stream_create_cu_mask(int n_cus, psg_stream_t* stream);
 int psg_stream_destroy(psg_stream_t stream);
 int psg_profile_begin(void);
 int psg_profile_end(double* ms, double* work, int64_t* launches, int nkinds);
+/* Algorithmic operand bytes (each input / output / weight element once) summed per family over the launches the last
+ * psg_profile_end() accounted for: printed beside the PMC traffic so the re-read ratio needs no derivation. */
+int psg_profile_bytes(double* bytes, int nkinds);
 
 #ifdef __cplusplus
 }

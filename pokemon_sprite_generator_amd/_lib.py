@@ -102,6 +102,7 @@ SIGNATURES = {
     "psg_stream_destroy": (c_int, [c_void_p]),
     "psg_profile_begin": (c_int, []),
     "psg_profile_end": (c_int, [c_void_p, c_void_p, c_void_p, c_int]),
+    "psg_profile_bytes": (c_int, [c_void_p, c_int]),
 }
 
 _lib = None

@@ -423,7 +423,7 @@ int psg_attn_fwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const v
     p.B = B; p.H = heads; p.L = L; p.S = S; p.d = d; p.scale = scale;
     p.drop_thresh = drop_p > 0.f ? drop_thresh(drop_p) : 0u; p.drop_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f; p.seed = seed; p.seed_dev = seed_source();
     dim3 grid((L + AT_Q - 1) / AT_Q, B * heads);
-    ProfScope prof(PROF_ATTN, 4.0 * (double)B * heads * L * S * d, (hipStream_t)stream);
+    ProfScope prof(PROF_ATTN, 4.0 * (double)B * heads * L * S * d, (hipStream_t)stream, (double)B * heads * d * (2.0 * L + 2.0 * S) * (dtype == PSG_BF16 ? 2.0 : 4.0));
     if ((g_attn_allow & 1) && attn_mfma_applicable(L, S, d, dtype, ldq, ldk, ldv, ldo) && aligned16(q) && aligned16(k) && aligned16(v) && aligned8(o)) {
         ++g_attn_paths[0];
         return attn_mfma_fwd(to_mfma(p), (hipStream_t)stream);
@@ -461,7 +461,7 @@ int psg_attn_bwd(const void* q, int64_t ldq, const void* k, int64_t ldk, const v
     const int64_t rows = (int64_t)B * heads * L;
     const int gdelta = (int)((rows + 3) / 4);
     dim3 gq((L + AT_Q - 1) / AT_Q, B * heads), gkv((S + AT_Q - 1) / AT_Q, B * heads);
-    ProfScope prof(PROF_ATTN, 10.0 * (double)B * heads * L * S * d, s);
+    ProfScope prof(PROF_ATTN, 10.0 * (double)B * heads * L * S * d, s, (double)B * heads * d * (4.0 * L + 4.0 * S) * (dtype == PSG_BF16 ? 2.0 : 4.0));
     if ((g_attn_allow & 1) && attn_mfma_applicable(L, S, d, dtype, ldq, ldk, ldv, ldo) && ((lddo | lddq | lddk | lddv) & 7) == 0 && aligned16(q) && aligned16(k) &&
         aligned16(v) && aligned16(o) && aligned16(dout) && aligned8(dq) && aligned8(dk) && aligned8(dv)) {
         ++g_attn_paths[0];

@@ -914,7 +914,10 @@ int launch_conv(const ConvP& p, hipStream_t stream) {
     q.mtiles = (p.M + BM - 1) / BM;
     q.ntiles = (p.N + BN - 1) / BN;
     const int grid = q.mtiles * q.ntiles * (q.splits > 1 ? q.splits : 1);
-    ProfScope prof(p.transposed ? PROF_CONV_DGRAD : PROF_CONV_FWD, 2.0 * (double)p.M * (double)p.N * (double)p.taps * (double)p.Cin, stream);
+    // algorithmic bytes: every input pixel, weight and output element once (+ the epilogue's residual / saved tensors)
+    const double esz = (double)sizeof(T);
+    const double abytes = ((double)p.B * p.Hi * p.Wi * p.Cin + (double)p.N * p.taps * p.Cin + (double)p.M * p.N * (1.0 + (p.residual || p.dact_u ? 1.0 : 0.0) + (p.preact ? 1.0 : 0.0))) * esz;
+    ProfScope prof(p.transposed ? PROF_CONV_DGRAD : PROF_CONV_FWD, 2.0 * (double)p.M * (double)p.N * (double)p.taps * (double)p.Cin, stream, abytes);
     const ConvP fin = q;                               // (the finishing kernel runs the epilogue: it keeps the operands)
     if (q.splits > 1) { q.bias = nullptr; q.rowadd = nullptr; q.residual = nullptr; q.preact = nullptr; q.dact_u = nullptr; }
     const int mode = p.ntap > 0 ? 3 : (!p.fast ? 2 : (!p.transposed ? 0 : (p.stride == 1 ? 1 : 2)));

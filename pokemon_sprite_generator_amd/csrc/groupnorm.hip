@@ -691,7 +691,7 @@ int psg_groupnorm_fwd(const void* x, int64_t ldx, void* y, int64_t ldy, const fl
     hipStream_t s = (hipStream_t)stream;
     const int threads = p.CC * p.PP, grid = B * p.NS;
     const size_t lds1 = (size_t)p.PP * C * 2 * sizeof(float), lds2 = (size_t)G * 2 * sizeof(float);
-    ProfScope prof(PROF_GN, 2.0 * (double)B * HW * C * (double)(dtype == PSG_BF16 ? 2 : 4), s);
+    ProfScope prof(PROF_GN, 2.0 * (double)B * HW * C * (double)(dtype == PSG_BF16 ? 2 : 4), s, 2.0 * (double)B * HW * C * (double)(dtype == PSG_BF16 ? 2 : 4));
     {
         GnF f = {};
         f.x = x; f.y = y; f.gamma = gamma; f.beta = beta; f.mean = mean; f.rstd = rstd; f.ldx = ldx; f.ldy = ldy;
@@ -750,7 +750,7 @@ int psg_groupnorm_bwd_res(const void* dy, int64_t lddy, const void* x, int64_t l
     hipStream_t s = (hipStream_t)stream;
     const int threads = p.CC * p.PP, grid = B * p.NS;
     const size_t lds1 = (size_t)p.PP * C * 2 * sizeof(float), lds2 = ((size_t)C + G) * 2 * sizeof(float);
-    ProfScope prof(PROF_GN, (dres ? 4.0 : 3.0) * (double)B * HW * C * (double)(dtype == PSG_BF16 ? 2 : 4), s);
+    ProfScope prof(PROF_GN, (dres ? 4.0 : 3.0) * (double)B * HW * C * (double)(dtype == PSG_BF16 ? 2 : 4), s, (dres ? 4.0 : 3.0) * (double)B * HW * C * (double)(dtype == PSG_BF16 ? 2 : 4));
     {
         GnF f = {};
         f.x = x; f.dy = dy; f.dres = dres; f.dx = dx; f.gamma = gamma; f.beta = beta; f.mean = const_cast<float*>(mean);

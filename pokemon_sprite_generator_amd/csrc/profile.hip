@@ -9,7 +9,8 @@
 
 namespace psg {
 
-struct ProfRec { hipEvent_t a, b; int kind; double work; };
+struct ProfRec { hipEvent_t a, b; int kind; double work, bytes; };
+static double g_last_bytes[PROF_KINDS] = {0, 0, 0, 0, 0};
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_recs;
 static std::vector<hipEvent_t> g_pool;
@@ -22,10 +23,10 @@ static hipEvent_t take_event() {
     return e;
 }
 
-ProfScope::ProfScope(int kind, double work, hipStream_t stream) : idx_(-1), stream_(stream) {
+ProfScope::ProfScope(int kind, double work, hipStream_t stream, double bytes) : idx_(-1), stream_(stream) {
     if (!g_prof_on) return;
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    ProfRec r{take_event(), take_event(), kind, work};
+    ProfRec r{take_event(), take_event(), kind, work, bytes};
     if (!r.a || !r.b) return;
     hipEventRecord(r.a, stream);
     g_recs.push_back(r);
@@ -82,14 +83,23 @@ int psg_profile_end(double* ms, double* work, int64_t* launches, int nkinds) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
     g_prof_on = false;
     for (int k = 0; k < nkinds; ++k) { ms[k] = 0; work[k] = 0; launches[k] = 0; }
+    for (int k = 0; k < PROF_KINDS; ++k) g_last_bytes[k] = 0;
     for (auto& r : g_recs) {
         if (hipEventSynchronize(r.b) != hipSuccess) return hip_fail(hipGetLastError(), "profile_end sync");
         float t = 0.f;
         if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return hip_fail(hipGetLastError(), "profile_end elapsed");
         if (r.kind >= 0 && r.kind < nkinds) { ms[r.kind] += t; work[r.kind] += r.work; launches[r.kind] += 1; }
+        if (r.kind >= 0 && r.kind < PROF_KINDS) g_last_bytes[r.kind] += r.bytes;
         g_pool.push_back(r.a); g_pool.push_back(r.b);
     }
     g_recs.clear();
+    return PSG_OK;
+}
+
+int psg_profile_bytes(double* bytes, int nkinds) {
+    PSG_REQUIRE(bytes && nkinds > 0, PSG_ERR_ARG, "profile_bytes: null pointer");
+    std::lock_guard<std::mutex> lk(g_prof_mu);
+    for (int k = 0; k < nkinds; ++k) bytes[k] = k < PROF_KINDS ? g_last_bytes[k] : 0.0;
     return PSG_OK;
 }
 

@@ -40,7 +40,7 @@ int hip_fail(hipError_t e, const char* what);
 // bench-only timing of a kernel family (profile.hip); a no-op unless psg_profile_begin() was called
 enum ProfKind { PROF_CONV_FWD = 0, PROF_CONV_DGRAD = 1, PROF_WGRAD = 2, PROF_ATTN = 3, PROF_GN = 4, PROF_KINDS = 5 };
 struct ProfScope {
-    ProfScope(int kind, double work, hipStream_t stream);
+    ProfScope(int kind, double work, hipStream_t stream, double bytes = 0.0);   // bytes: the launch's ALGORITHMIC operand bytes
     ~ProfScope();
     int idx_;
     hipStream_t stream_;

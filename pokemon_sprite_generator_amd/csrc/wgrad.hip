@@ -1129,7 +1129,9 @@ int psg_conv_wgrad(const psg_wgrad_desc* d, psg_stream_t stream) {
                          p.Q, p.wide, p.BR, p.rtiles, p.qtiles, p.splits, p.steps_per_split, grid, (int)direct);
     }
     {
-        ProfScope prof(PROF_WGRAD, 2.0 * (double)p.M * (double)p.Cout * (double)p.Q, s);
+        const double esz = d->dtype == PSG_BF16 ? 2.0 : 4.0;
+        ProfScope prof(PROF_WGRAD, 2.0 * (double)p.M * (double)p.Cout * (double)p.Q, s,
+                       ((double)d->B * d->Hi * d->Wi * d->Cin + (double)p.M * d->Cout) * esz + (double)d->Cout * p.Q * 4.0);
         const int geom = d->stride != 1 || d->Hi != d->Ho || d->Wi != d->Wo ? 0 : (d->ksize == 1 ? 2 : 1);
 #define PSG_WG_LAUNCH(G)                                                                                               \
         if (d->dtype == PSG_BF16) hipLaunchKernelGGL((wgrad_kernel<bf16_t, G>), dim3(grid), dim3(256), 4 * 64 * 256, s, p); \
