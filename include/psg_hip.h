@@ -234,6 +234,11 @@ typedef struct psg_conv_desc {
 } psg_conv_desc;
 int psg_conv_fwd(const psg_conv_desc* d, psg_stream_t stream);
 int64_t psg_conv_fwd_workspace_bytes(const psg_conv_desc* d);   /* 0: the launch would not be split; < 0: bad descriptor */
+/* Diagnostics: psg_conv_fwd runs pointwise layers (1x1 / Linear, bf16, whole 128 x 128 tiles, >= 1.5 tiles per resident
+ * workgroup slot) on the persistent kernel of csrc/conv_pw.hip - same arithmetic, same bits.  psg_conv_set_pw(0) sends them
+ * to the per-tile kernel instead (A/B runs, the bitwise test); psg_conv_pw_launches counts launches the persistent kernel took. */
+int psg_conv_set_pw(int on);
+int64_t psg_conv_pw_launches(void);
 
 /* Weight gradient — convolution_backward's wgrad for the same layers.
  * dw (fp32) = sum_m dy[m,co] * x[pix(m,kh,kw), ci], stored in the parameter's own memory order:

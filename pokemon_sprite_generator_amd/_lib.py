@@ -78,6 +78,8 @@ SIGNATURES = {
     "psg_groupnorm_bwd_workspace_bytes": (c_int64, [c_int, c_int]),
     "psg_conv_fwd": (c_int, [C.POINTER(ConvDesc), c_void_p]),
     "psg_conv_fwd_workspace_bytes": (c_int64, [C.POINTER(ConvDesc)]),
+    "psg_conv_set_pw": (c_int, [c_int]),
+    "psg_conv_pw_launches": (c_int64, []),
     "psg_conv_wgrad": (c_int, [C.POINTER(WgradDesc), c_void_p]),
     "psg_conv_wgrad_workspace_bytes": (c_int64, [C.POINTER(WgradDesc)]),
     "psg_prep_weight": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),

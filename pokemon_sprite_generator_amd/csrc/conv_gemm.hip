@@ -14,6 +14,11 @@ PSG_TILE_DECL(bf16_t, 128, 160) PSG_TILE_DECL(bf16_t, 64, 160)
 #undef PSG_TILE_DECL
 
 
+// persistent pointwise kernel (conv_pw.hip)
+bool conv_pw_applicable(const ConvP& p, int dtype);
+int launch_conv_pw(const ConvP& p, hipStream_t stream);
+int conv_pw_set_attrs();
+
 // tile choice: maximise (useful fraction of the tile grid) x (chip fill of the last wave) x (tile efficiency); then, for
 // grids that leave most of the chip idle (small M: sampling, small batches), split-K on top
 struct ConvPlan { int BM, BN, splits, kt_per_split; };
@@ -91,6 +96,10 @@ static int choose_and_launch(const ConvP& p0, int dtype, hipStream_t s) {
         if (dbg) fprintf(stderr, "psg conv: M=%d N=%d Cin=%d ks=%d tr=%d fast=%d epi_lds=%d -> tile %dx%d splits=%d\n", p.M, p.N, p.Cin, p.ks, p.transposed,
                          p.fast, p.epi_lds, BM, BN, p.splits);
     }
+    if (BM == 128 && BN == 128 && p.splits == 1 && conv_pw_applicable(p, dtype)) {
+        const int rc = launch_conv_pw(p, s);
+        if (rc != -1) return rc;
+    }
     if (BN == 160 && BM == 64) return launch_conv<bf16_t, 64, 160>(p, s);
     if (BN == 160) return launch_conv<bf16_t, 128, 160>(p, s);
     if (dtype == PSG_F32) {
@@ -119,6 +128,7 @@ int psg_conv_init_attrs(void) {
     if ((rc = set_conv_attrs<bf16_t, 64, 64>())) return rc;
     if ((rc = set_conv_attrs<bf16_t, 128, 160>())) return rc;
     if ((rc = set_conv_attrs<bf16_t, 64, 160>())) return rc;
+    if ((rc = conv_pw_set_attrs())) return rc;
     return PSG_OK;
 }
 

@@ -403,6 +403,82 @@ def test_conv_linearity_full_size(psg):
     assert maxrel(from_cl(y1[idx].cpu()), ref) < 2e-2
 
 
+# ---------------------------------------------------------------- persistent pointwise kernel (csrc/conv_pw.hip)
+def _pw(on):
+    from pokemon_sprite_generator_amd import _lib
+    _lib.check(_lib.init(0).psg_conv_set_pw(int(on)), "psg_conv_set_pw")
+
+
+def _pw_count():
+    from pokemon_sprite_generator_amd import _lib
+    return int(_lib.init(0).psg_conv_pw_launches())
+
+
+@pytest.mark.parametrize("M,K,N", [(12800, 256, 1024), (50176, 640, 640), (8192, 1280, 2560)])
+def test_pointwise_persistent_kernel_is_bitwise_the_tiled_kernel(psg, M, K, N):
+    """conv_pw_kernel (persistent workgroups, next tile's K slices requested before the epilogue, strip-staged stores, counted
+    vmcnt waits) against conv_gemm_kernel on the same launches: every epilogue kind the U-Net's Linears use - bias, gate +
+    residual, dropout + residual, GELU + dropout + saved derivative (two outputs), the derivative-multiplying data gradient,
+    plain data gradients - forward AND backward results must be identical BIT FOR BIT (same MFMA order, same epilogue
+    arithmetic), and the persistent kernel must really have taken the launches.  Reference check of the same ops: test_linear_epilogue,
+    test_ffn_gelu_dropout_backward (small M, tiled kernel) - so equality here carries their parity over."""
+    from pokemon_sprite_generator_amd import ops
+    dt = torch.bfloat16
+    g = torch.Generator(device=DEV).manual_seed(M + K)
+    x = torch.randn(M, K, device=DEV, generator=g).to(dt)
+    res = torch.randn(M, N, device=DEV, generator=g).to(dt)
+    w = (torch.randn(N, K, device=DEV, generator=g) * math.sqrt(1.0 / K))
+    b = torch.randn(N, device=DEV, generator=g) * 0.3
+    gy = torch.randn(M, N, device=DEV, generator=g).to(dt)
+    w1 = torch.randn(2 * K, K, device=DEV, generator=g) * math.sqrt(1.0 / K)
+    b1 = torch.randn(2 * K, device=DEV, generator=g) * 0.3
+    w2 = torch.randn(K, 2 * K, device=DEV, generator=g) * math.sqrt(0.5 / K)
+    b2 = torch.randn(K, device=DEV, generator=g) * 0.3
+    gx = torch.randn(M, K, device=DEV, generator=g).to(dt)
+
+    def run():
+        outs = []
+        xs = x.clone().requires_grad_(True)
+        rs = res.clone().requires_grad_(True)
+        y = ops.linear(xs, w.clone().requires_grad_(True), b.clone().requires_grad_(True))                     # bias only
+        y.backward(gy)
+        outs += [y.detach(), xs.grad.clone()]
+        xs.grad = None
+        ws, bs = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        y = ops.linear(xs, ws, bs, residual=rs, alpha=0.7)                                                     # out-proj form
+        y.backward(gy)
+        outs += [y.detach(), xs.grad.clone(), rs.grad.clone(), ws.grad.clone(), bs.grad.clone()]
+        xs.grad = None
+        y = ops.linear(xs, w.clone().requires_grad_(True), b.clone().requires_grad_(True), residual=rs, alpha=0.6, drop_p=0.05, seed=991)
+        y.backward(gy)
+        outs += [y.detach(), xs.grad.clone()]
+        xs.grad = None
+        y = ops.linear(xs, w.clone().requires_grad_(True), b.clone().requires_grad_(True), act=ops.ACT_GELU)
+        y.backward(gy)
+        outs += [y.detach(), xs.grad.clone()]
+        xs.grad = None
+        p1 = [t.clone().requires_grad_(True) for t in (w1, b1, w2, b2)]
+        y = ops.ffn(xs, p1[0], p1[1], p1[2], p1[3], 0.6, drop_p=0.05, seed1=17, seed2=18)                      # fused FFN node (train mode)
+        y.backward(gx)
+        outs += [y.detach(), xs.grad.clone()] + [t.grad.clone() for t in p1]
+        torch.cuda.synchronize()
+        return outs
+
+    try:
+        _pw(0)
+        c0 = _pw_count()
+        ref = run()
+        assert _pw_count() == c0
+        _pw(1)
+        got = run()
+        assert _pw_count() - c0 >= 10, _pw_count() - c0          # forwards and data gradients of all five forms
+    finally:
+        _pw(1)
+    for i, (a, r) in enumerate(zip(got, ref)):
+        assert torch.isfinite(r.float()).all()
+        assert torch.equal(a, r), (i, float((a.float() - r.float()).abs().max()))
+
+
 # ---------------------------------------------------------------- attention core
 ATTN_CASES = [  # B, heads, L, S, d, self
     (2, 8, 16, 16, 16, True), (2, 4, 49, 49, 32, True), (1, 8, 196, 196, 80, True), (2, 8, 16, 32, 160, False),
