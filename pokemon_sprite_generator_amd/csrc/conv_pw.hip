@@ -31,6 +31,9 @@ __device__ __forceinline__ void pw_load8(u32x2& r, const u32x4& rsrc, uint32_t v
 __device__ __forceinline__ void pw_load16(f32x4& r, const u32x4& rsrc, uint32_t voff) {
     asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(r) : "v"(voff), "s"(rsrc) : "memory");
 }
+__device__ __forceinline__ void pw_load16u(u32x4& r, const u32x4& rsrc, uint32_t voff) {      // (the destination is written by the
+    asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(r) : "v"(voff), "s"(rsrc) : "memory");   //  load itself: no copy may sit between it and its wait)
+}
 template <typename V> __device__ __forceinline__ void pw_tie(V& r) { asm volatile("" : "+v"(r)); }
 
 // EK: epilogue kind of conv_gemm_kernel.h.  HAS_AUX: a residual (added) or, for EK_DMUL, the saved derivative (multiplied).
@@ -164,18 +167,21 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvP p, const in
         const int endpar = (par + KT) & 1;              // buffer after the last one = next tile's slice 0
         if (more) request(nxt, 0, endpar);
         f32x4 bias4[NA];
-        u32x2 aux[NA][NB];
+        // aux operand (residual / saved derivative) of the wave's 64 x 64 sub-tile, ROW-major: 16 bytes per lane, 8 whole
+        // 128-byte rows per instruction (as 8-byte pieces in the accumulator layout - 16 rows x 32 bytes per instruction -
+        // the same bytes took twice the load instructions and four times the line requests, under the K loop's own DMA
+        // stream: every layer with a residual got SLOWER than on the per-tile kernel); it is turned into the accumulator
+        // layout strip by strip through the wave's staging strip
+        u32x4 auxr[8];
         if (p.bias) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) pw_load16(bias4[i], brs, (uint32_t)(n0 + wn * WN + i * 16 + 4 * kq) * 4u);
         }
         if (HAS_AUX) {
+            const uint32_t rowb = (uint32_t)(((int64_t)(m0 + wm * WM + (lane >> 3)) * ldaux + n0 + wn * WN + (lane & 7) * 8) * 2);
+            const uint32_t step8 = (uint32_t)(ldaux * 16);                 // 8 rows further
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                const uint32_t rowb = (uint32_t)(((int64_t)(m0 + wm * WM + j * 16 + l16) * ldaux + n0 + wn * WN + 4 * kq) * 2);
-#pragma unroll
-                for (int i = 0; i < NA; ++i) pw_load8(aux[i][j], ars, rowb + (uint32_t)(i * 32));
-            }
+            for (int it = 0; it < 8; ++it) pw_load16u(auxr[it], ars, rowb + (uint32_t)it * step8);
         }
         compute((par + KT - 1) & 1);
         pw_barrier();                                   // every wave is done with the last slice's buffer
@@ -191,13 +197,21 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvP p, const in
         }
         if (HAS_AUX) {
 #pragma unroll
-            for (int j = 0; j < NB; ++j)
-#pragma unroll
-                for (int i = 0; i < NA; ++i) pw_tie(aux[i][j]);
+            for (int it = 0; it < 8; ++it) pw_tie(auxr[it]);
         }
         // ---- epilogue: one 16-pixel strip of the wave's 64 x 64 sub-tile at a time ----
         T* yg = reinterpret_cast<T*>(p.y);
         T* pg = reinterpret_cast<T*>(p.preact);
+        // rows -> accumulator cells of strip j through the staging strip (LDS operations of a wave execute in order: the
+        // writes may follow the previous strip's row reads without a wait, the cell reads follow the writes)
+        u32x2 auxc[2][NA];
+        auto aux_cells = [&](int j, u32x2 (&c)[NA]) {
+            *reinterpret_cast<u32x4*>(strip + (lane >> 3) * PITCH + (lane & 7) * 16) = auxr[2 * j];
+            *reinterpret_cast<u32x4*>(strip + (8 + (lane >> 3)) * PITCH + (lane & 7) * 16) = auxr[2 * j + 1];
+#pragma unroll
+            for (int i = 0; i < NA; ++i) c[i] = *reinterpret_cast<const u32x2*>(strip + l16 * PITCH + (i * 16 + 4 * kq) * 2);
+        };
+        if (HAS_AUX) aux_cells(0, auxc[0]);
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
             const int m = m0 + wm * WM + j * 16 + l16;
@@ -207,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvP p, const in
                 const int n = n0 + wn * WN + i * 16 + 4 * kq;
                 f32x4 a4 = zero4;
                 if (HAS_AUX) {
-                    const uint32_t lo = aux[i][j].x, hi = aux[i][j].y;
+                    const uint32_t lo = auxc[j & 1][i].x, hi = auxc[j & 1][i].y;
                     a4[0] = __uint_as_float(lo << 16); a4[1] = __uint_as_float(lo & 0xFFFF0000u);
                     a4[2] = __uint_as_float(hi << 16); a4[3] = __uint_as_float(hi & 0xFFFF0000u);
                 }
@@ -223,6 +237,7 @@ __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvP p, const in
                 T* base = dst + (int64_t)(m0 + wm * WM + j * 16) * ldd + (n0 + wn * WN);
                 uint4 c0 = *reinterpret_cast<const uint4*>(strip + (lane >> 3) * PITCH + (lane & 7) * 16);
                 uint4 c1 = *reinterpret_cast<const uint4*>(strip + (8 + (lane >> 3)) * PITCH + (lane & 7) * 16);
+                if (HAS_AUX && j + 1 < NB) aux_cells(j + 1, auxc[(j + 1) & 1]);      // (behind the row reads, ahead of the stores)
                 *reinterpret_cast<uint4*>(base + (int64_t)(lane >> 3) * ldd + (lane & 7) * 8) = c0;
                 *reinterpret_cast<uint4*>(base + (int64_t)(8 + (lane >> 3)) * ldd + (lane & 7) * 8) = c1;
             };

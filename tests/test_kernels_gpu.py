@@ -414,7 +414,7 @@ def _pw_count():
     return int(_lib.init(0).psg_conv_pw_launches())
 
 
-@pytest.mark.parametrize("M,K,N", [(12800, 256, 1024), (50176, 640, 640), (8192, 1280, 2560)])
+@pytest.mark.parametrize("M,K,N", [(12800, 256, 1024), (50176, 640, 640), (12544, 1280, 1280)])
 def test_pointwise_persistent_kernel_is_bitwise_the_tiled_kernel(psg, M, K, N):
     """conv_pw_kernel (persistent workgroups, next tile's K slices requested before the epilogue, strip-staged stores, counted
     vmcnt waits) against conv_gemm_kernel on the same launches: every epilogue kind the U-Net's Linears use - bias, gate +
@@ -471,7 +471,9 @@ def test_pointwise_persistent_kernel_is_bitwise_the_tiled_kernel(psg, M, K, N):
         assert _pw_count() == c0
         _pw(1)
         got = run()
-        assert _pw_count() - c0 >= 10, _pw_count() - c0          # forwards and data gradients of all five forms
+        # (a launch qualifies with >= 768 output tiles: at the small shape only the four plain forwards do, at 14x14x640 the
+        #  forwards, the data gradients and all four GEMMs of the FFN node)
+        assert _pw_count() - c0 >= {12800: 4, 12544: 12, 50176: 12}[M], _pw_count() - c0
     finally:
         _pw(1)
     for i, (a, r) in enumerate(zip(got, ref)):
