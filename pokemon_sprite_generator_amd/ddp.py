@@ -166,8 +166,9 @@ class BucketedAllReduce:
         self.buckets = []          # (start, end, [param indices])
         cap = max(1, bucket_bytes // 4)
         start, members = 0, []
-        for i, (p, o) in enumerate(zip(params, offsets)):
-            end = offsets[i + 1] if i + 1 < len(offsets) else self.flat.numel()      # (includes the alignment gap)
+        order = sorted(range(len(offsets)), key=lambda i: offsets[i])            # memory order (an arena may use its own layout)
+        for pos, i in enumerate(order):
+            end = offsets[order[pos + 1]] if pos + 1 < len(order) else self.flat.numel()      # (includes the alignment gap)
             members.append(i)
             if end - start >= cap:
                 self.buckets.append((start, end, members))

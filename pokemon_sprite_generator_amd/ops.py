@@ -835,6 +835,109 @@ def cross_in_proj(xn, tp, weight, bias):
 
 
 # ---------------------------------------------------------------------------
+# the 17 ResBlocks' time_proj / text_proj as TWO GEMMs (unet.py:83-86,119-124)
+# ---------------------------------------------------------------------------
+class _SplitColsFn(torch.autograd.Function):
+    """[B, sum C] -> 17 column slices (views); backward = ONE concatenation of the 17 gradients (autograd's own slice nodes
+    would each allocate and fill a zero [B, sum C] tensor)."""
+
+    @staticmethod
+    def forward(ctx, x, bounds):
+        ctx.bounds, ctx.shape = bounds, tuple(x.shape)
+        return tuple(x[:, a:b] for a, b in bounds)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        if any(g is None for g in grads):
+            full = torch.zeros(ctx.shape, dtype=next(g for g in grads if g is not None).dtype, device=next(g for g in grads if g is not None).device)
+            for (a, b), g in zip(ctx.bounds, grads):
+                if g is not None:
+                    full[:, a:b] = g
+            return full, None
+        return torch.cat(grads, dim=1), None
+
+
+class ProjGroup:
+    """`h += time_proj(temb) + text_proj(pooled)` of every ResBlock (unet.py:119-124) depends only on temb / pooled: with the 17
+    weights of a kind ADJACENT in the parameter arena (UNet.arena_layout) they are one [sum Cout, K] operand, and the 34 tiny
+    M = batch GEMMs of a forward (+ 34 data gradients, 34 weight gradients and the 32 accumulation adds of temb's / pooled's
+    gradients in backward) become two Linear nodes over VIRTUAL parameters: leaf views of the flat master buffer whose
+    gradient sink is the matching run of the gradient arena and whose prepared bf16 operand is the matching run of the AdamW
+    shadow.  state_dict, the optimizer and the all-reduce never see them - they see the 68 real parameters, which are marked
+    written (and reported to the data-parallel reducer) when the group's gradient lands."""
+
+    def __init__(self, blocks, param_arena, grad_arena):
+        self.ok = False
+        self.blocks = list(blocks)
+        pidx = {id(p): i for i, p in enumerate(param_arena.params)}
+        self.pa, self.ga = param_arena, grad_arena
+        self.virtual = []                       # (w_all, b_all) per kind
+        self.bounds, off = [], 0
+        for blk in self.blocks:
+            self.bounds.append((off, off + blk.out_channels))
+            off += blk.out_channels
+        self.width = off
+        self.members = []
+        for kind in ("time_proj", "text_proj"):
+            ws, bs = [getattr(b, kind).weight for b in self.blocks], [getattr(b, kind).bias for b in self.blocks]
+            if any(id(t) not in pidx for t in ws + bs):
+                return
+            wi, bi = tuple(pidx[id(t)] for t in ws), tuple(pidx[id(t)] for t in bs)
+            for idx in (wi, bi):                # one contiguous run each, in block order, in BOTH arenas
+                for a, b in zip(idx[:-1], idx[1:]):
+                    if param_arena.offsets[b] != param_arena.offsets[a] + param_arena.params[a].numel() or grad_arena.offsets[b] != param_arena.offsets[b]:
+                        return
+            K = ws[0].shape[1]
+            ow, ob = param_arena.offsets[wi[0]], param_arena.offsets[bi[0]]
+            w_all = param_arena.flat[ow:ow + self.width * K].view(self.width, K).requires_grad_(True)
+            b_all = param_arena.flat[ob:ob + self.width].requires_grad_(True)
+            gw = grad_arena.flat[ow:ow + self.width * K].view(self.width, K)
+            gb = grad_arena.flat[ob:ob + self.width]
+            for virt, view, idx in ((w_all, gw, wi), (b_all, gb, bi)):
+                ents = [grad_arena.entries[i] for i in idx]
+                ve = GradSink.register(virt, view, -1, on_ready=(lambda _i, ents=ents: [GradSink.done(e) for e in ents]), owner=grad_arena)
+                grad_arena.extra_entries.append(ve)
+                ParamShadow.register(virt, param_arena, idx)
+            self.virtual.append((w_all, b_all))
+            self.members.append(ws + bs)
+        self._versions = self._member_versions()
+        self.ok = True
+
+    def _member_versions(self):
+        return tuple(p._version for m in self.members for p in m)
+
+    def usable(self):
+        """Both arenas still own the parameters, and a member changed behind the optimizer's back (load_state_dict, an in-place
+        torch op: its own version counter, which the virtual views do not share) drops the group's prepared operands."""
+        if not self.ok or self.pa._displaced_by is not None or self.ga._displaced:
+            return False
+        v = self._member_versions()
+        if v != self._versions:
+            self._versions = v
+            WeightCache.drop([t for pair in self.virtual for t in pair])
+        return True
+
+    def release(self):
+        WeightCache.drop([t for pair in self.virtual for t in pair])
+        for pair in self.virtual:
+            for t in pair:
+                e = GradSink._map.pop(id(t), None)
+                if e is not None and e in self.ga.extra_entries:
+                    self.ga.extra_entries.remove(e)
+                ParamShadow._map.pop(id(t), None)
+        self.ok = False
+
+    def rowadds(self, temb, pooled):
+        """The 17 per-sample additive vectors [B, Cout_k] (views of one [B, sum Cout] result)."""
+        (wt, bt), (wx, bx) = self.virtual
+        ra = linear(temb, wt, bt)
+        ra = linear(pooled, wx, bx, residual=ra)
+        if torch.is_grad_enabled() and ra.requires_grad:
+            return _SplitColsFn.apply(ra, tuple(self.bounds))
+        return tuple(ra[:, a:b] for a, b in self.bounds)
+
+
+# ---------------------------------------------------------------------------
 # GroupNorm (+SiLU)
 # ---------------------------------------------------------------------------
 class _GroupNormFn(torch.autograd.Function):

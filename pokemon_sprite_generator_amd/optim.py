@@ -26,11 +26,17 @@ from ._lib import check, ptr, stream_ptr
 from .ops import GradSink, ParamShadow, SideStream, WeightCache
 
 
-def _arena_offsets(params):
-    offsets, off = [], 0
-    for p in params:
-        offsets.append(off)
-        off += (p.numel() + 7) // 8 * 8              # 32-byte steps: fp32 views and their bf16 shadows stay 16-byte aligned
+def _arena_offsets(params, layout=None):
+    """offsets[i] of parameter i in the flat buffer.  `layout` (a permutation of the parameter indices) is the MEMORY order -
+    by default the parameter order; a model may ask for another one (UNet.arena_layout puts the 17 time_proj / text_proj
+    weights next to each other so that they are ONE [sum Cout, K] operand: ops.ProjGroup)."""
+    order = list(range(len(params))) if layout is None else list(layout)
+    if sorted(order) != list(range(len(params))):
+        raise ValueError("arena layout must be a permutation of the parameter indices")
+    offsets, off = [0] * len(params), 0
+    for i in order:
+        offsets[i] = off
+        off += (params[i].numel() + 7) // 8 * 8      # 32-byte steps: fp32 views and their bf16 shadows stay 16-byte aligned
     return offsets, off
 
 
@@ -44,12 +50,12 @@ class ParamArena:
 
     _owner = {}          # id(param) -> weakref(ParamArena) that currently backs the parameter's storage
 
-    def __init__(self, params):
+    def __init__(self, params, layout=None):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("ParamArena: no trainable parameters")
         dev = self.params[0].device
-        self.offsets, self.numel = _arena_offsets(self.params)
+        self.offsets, self.numel = _arena_offsets(self.params, layout)
         self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
         self._displaced_by = None
         me = weakref.ref(self)
@@ -109,6 +115,11 @@ class ParamArena:
     def shadow_slice(self, index):
         if self.shadow is None or self._shadow_epoch != WeightCache.epoch:
             return None
+        if isinstance(index, tuple):                 # (member indices of a contiguous run): the shadow of the whole run
+            if any(self.params[i]._version != self._versions[i] for i in index):
+                return None
+            o0, last = self.offsets[index[0]], index[-1]
+            return self.shadow[o0:self.offsets[last] + self.params[last].numel()]
         p = self.params[index]
         if p._version != self._versions[index]:
             return None
@@ -132,17 +143,18 @@ class ParamArena:
 
 
 class GradArena:
-    def __init__(self, params, on_ready=None):
+    def __init__(self, params, on_ready=None, layout=None):
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("GradArena: no trainable parameters")
         dev = self.params[0].device
-        self.offsets, self.numel = _arena_offsets(self.params)
+        self.offsets, self.numel = _arena_offsets(self.params, layout)
         self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
         self.normsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self.on_ready = on_ready
         self.views = []
         self.entries = []
+        self.extra_entries = []            # sinks of virtual parameters over runs of this arena (ops.ProjGroup): reset with ours
         self._displaced = False
         for i, (p, o) in enumerate(zip(self.params, self.offsets)):
             v = self.flat.as_strided(p.shape, p.stride(), o)      # the parameter's own memory order
@@ -176,6 +188,8 @@ class GradArena:
         """Start of a step: nothing is memset — every sink is overwritten by its first gradient kernel."""
         self.check_alive()
         for e in self.entries:
+            e.written = False
+        for e in self.extra_entries:
             e.written = False
         for p, v in zip(self.params, self.views):       # re-attach if someone set grads to None
             if p.grad is not v:

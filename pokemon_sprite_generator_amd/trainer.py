@@ -76,12 +76,15 @@ class DiffusionStepper:
         if distributed is None:
             distributed = torch.distributed.is_available() and torch.distributed.is_initialized()
         distributed = bool(distributed)
-        self.params = ParamArena(unet.parameters())        # flat fp32 masters, conv weights OHWI
+        # memory order of the two arenas: the model may ask for one (UNet.arena_layout: the time / text projections adjacent)
+        layout = unet.arena_layout([p for p in unet.parameters() if p.requires_grad]) if hasattr(unet, "arena_layout") else None
+        self.params = ParamArena(unet.parameters(), layout=layout)        # flat fp32 masters, conv weights OHWI
         if distributed:
             self.params.broadcast(src=0)                    # replicas equal by construction, not by RNG seeding
         if getattr(unet, "compute_dtype", None) == torch.bfloat16 and optimizer_type == "adamw" and not os.environ.get("PSG_NO_SHADOW"):
             self.params.enable_shadow()                     # AdamW also emits next step's bf16 forward weights
-        self.arena = GradArena(unet.parameters(), on_ready=lambda i: self.reducer.on_ready(i) if self.reducer is not None else None)
+        self.arena = GradArena(unet.parameters(), on_ready=lambda i: self.reducer.on_ready(i) if self.reducer is not None else None,
+                               layout=layout)
         # Adam (non-decoupled decay) is torch's when asked for (:285-291); AdamW is the fused kernel (:277-283)
         if optimizer_type == "adamw":
             self.optimizer = FusedAdamW(self.arena.params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay,
@@ -91,6 +94,8 @@ class DiffusionStepper:
         self.reducer = BucketedAllReduce(self.arena.flat, self.arena.params, self.arena.offsets, bucket_bytes,
                                          bucket_dtype=grad_bucket_dtype, force_single=force_single,
                                          cu_reserve=ddp_cu_reserve) if distributed else None
+        if hasattr(unet, "bind_proj_group"):
+            unet.bind_proj_group(self.params, self.arena)       # (after enable_shadow: the group's bf16 operand is a run of it)
         self.flag = torch.zeros(1, dtype=torch.int32, device=self.device)      # bits: enum psg_flag (include/psg_hip.h)
         self.loss = torch.zeros(1, dtype=torch.float32, device=self.device)
         self.criterion_beta = 0.1                                               # nn.SmoothL1Loss(beta=0.1) :300
@@ -103,6 +108,8 @@ class DiffusionStepper:
         """Release the process-wide registrations (gradient sinks, bf16 shadow, the graph-replay seed word) of this stepper."""
         for g in list(self._graphs):               # (each holds one count of the seed source and its capture stream's workspace)
             g.close()
+        if hasattr(self.unet, "bind_proj_group") and getattr(self.unet, "_proj_group", None) is not None and self.unet._proj_group.ga is self.arena:
+            self.unet.bind_proj_group(None, None)
         self.arena.release()
         self.params.release()
 

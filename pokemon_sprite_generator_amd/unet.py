@@ -22,6 +22,7 @@ from . import ops
 from .ops import ACT_GELU, ACT_NONE, ACT_SILU
 
 _FUSED_FFN = os.environ.get("PSG_FFN_FUSE", "1") != "0"
+_PROJ_GROUP = os.environ.get("PSG_PROJ_GROUP", "1") != "0"         # 0: every ResBlock runs its own time_proj / text_proj GEMMs (A/B)
 _CONCAT_SLOTS = os.environ.get("PSG_CONCAT_SLOTS", "1") != "0"     # 0: torch.cat in the decoder, autograd sums the skip gradients (A/B)
 
 ATTN_DROPOUT = 0.05   # nn.MultiheadAttention(dropout=0.05), nn.Dropout(0.05): unet.py:160-187
@@ -105,13 +106,15 @@ class ResBlock(nn.Module):
         self.skip_conv = nn.Conv2d(in_channels, out_channels, kernel_size=1) if in_channels != out_channels else nn.Identity()
         self.compute_dtype = torch.float32
 
-    def nhwc(self, x, temb, pooled, out=None):
-        """x [B,H,W,Cin], temb [B,128], pooled [B,256] in the compute dtype; `out`: ops.OutSlot for the result."""
+    def nhwc(self, x, temb, pooled, out=None, ra=None):
+        """x [B,H,W,Cin], temb [B,128], pooled [B,256] in the compute dtype; `out`: ops.OutSlot for the result; `ra`: the
+        per-sample additive vector when the caller computed it for all blocks at once (ops.ProjGroup)."""
         # (h, x): x's second consumer below is the skip path - its gradient joins inside the GroupNorm backward
         h, x = ops.group_norm_split(x, self.norm1.weight, self.norm1.bias, self.norm1.num_groups, self.norm1.eps, silu=True)
         # per-sample additive vector: time_proj(temb) + text_proj(pooled)  (unet.py:119-124), fused into conv1's epilogue
-        ra = ops.linear(temb, self.time_proj.weight, self.time_proj.bias)
-        ra = ops.linear(pooled, self.text_proj.weight, self.text_proj.bias, residual=ra)
+        if ra is None:
+            ra = ops.linear(temb, self.time_proj.weight, self.time_proj.bias)
+            ra = ops.linear(pooled, self.text_proj.weight, self.text_proj.bias, residual=ra)
         h = ops.conv2d(h, self.conv1.weight, self.conv1.bias, rowadd=ra)
         h = ops.group_norm(h, self.norm2.weight, self.norm2.bias, self.norm2.num_groups, self.norm2.eps, silu=True)
         if isinstance(self.skip_conv, nn.Conv2d):
@@ -193,10 +196,10 @@ class UNetBlock(nn.Module):
             self.attn_block = CrossAttentionBlock(out_channels, text_emb_dim, num_heads)
         self.compute_dtype = torch.float32
 
-    def nhwc(self, x, temb, pooled, text, out=None):
+    def nhwc(self, x, temb, pooled, text, out=None, ra=None):
         if not self.has_attention:
-            return self.res_block.nhwc(x, temb, pooled, out=out)
-        x = self.res_block.nhwc(x, temb, pooled)
+            return self.res_block.nhwc(x, temb, pooled, out=out, ra=ra)
+        x = self.res_block.nhwc(x, temb, pooled, ra=ra)
         return self.attn_block.nhwc(x, text, out=out)
 
     def forward(self, x, time_emb, text_emb, text_seq):
@@ -244,6 +247,42 @@ class UNet(nn.Module):
         self._initialize_weights()
         self.set_compute_dtype(compute_dtype)
 
+    def blocks_in_order(self):
+        """The 17 UNetBlocks in forward order."""
+        out = []
+        for lvl in range(4):
+            out += list(getattr(self, f"enc_block{lvl}"))
+        out.append(self.middle_block)
+        for lvl in (3, 2, 1, 0):
+            out += list(getattr(self, f"dec_block{lvl}"))
+        return out
+
+    def arena_layout(self, params):
+        """Memory order of the flat parameter / gradient arenas (optim._arena_offsets): the ResBlocks' time_proj weights next
+        to each other in block order, then their biases, text_proj likewise (ops.ProjGroup: two GEMMs instead of 34), then
+        everything else in parameter order.  They come FIRST: their gradients are the last backward produces, like those of the
+        time-embedding MLP and init_conv that follow - the data-parallel buckets leave in reverse memory order."""
+        params = list(params)
+        pidx = {id(p): i for i, p in enumerate(params)}
+        head = []
+        for kind, attr in (("time_proj", "weight"), ("time_proj", "bias"), ("text_proj", "weight"), ("text_proj", "bias")):
+            for b in self.blocks_in_order():
+                t = getattr(getattr(b.res_block, kind), attr)
+                if id(t) not in pidx:
+                    return None
+                head.append(pidx[id(t)])
+        taken = set(head)
+        return head + [i for i in range(len(params)) if i not in taken]
+
+    def bind_proj_group(self, param_arena, grad_arena):
+        """Called by the stepper once both arenas exist; `None` arenas unbind."""
+        if getattr(self, "_proj_group", None) is not None:
+            self._proj_group.release()
+        self._proj_group = None
+        if param_arena is not None and _PROJ_GROUP:
+            g = ops.ProjGroup([b.res_block for b in self.blocks_in_order()], param_arena, grad_arena)
+            self._proj_group = g if g.ok else None
+
     def set_compute_dtype(self, dtype):
         if dtype not in (torch.float32, torch.bfloat16):
             raise ValueError(f"compute_dtype must be torch.float32 or torch.bfloat16, got {dtype}")
@@ -279,6 +318,10 @@ class UNet(nn.Module):
         temb = self.time_embed.embed(timesteps, dt)
         pooled, text = ops.text_pool(text_emb, dt)
         x = ops.conv2d(x, self.init_conv.weight, self.init_conv.bias)
+        # per-sample additive vectors of all 17 ResBlocks in two GEMMs when the parameters live in a stepper's arenas
+        grp = getattr(self, "_proj_group", None)
+        ras = iter(grp.rowadds(temb, pooled)) if (grp is not None and grp.usable()) else None
+        nra = (lambda: next(ras)) if ras is not None else (lambda: None)
         skips = []
         slots = _CONCAT_SLOTS and all(len(getattr(self, f"dec_block{lvl}")) == 2 for lvl in range(4))
         for lvl in range(4):
@@ -286,7 +329,7 @@ class UNet(nn.Module):
                 ds = getattr(self, f"downsample{lvl}")
                 x = ops.conv2d(x, ds.weight, ds.bias, stride=2)
             for blk in getattr(self, f"enc_block{lvl}"):
-                x = blk.nhwc(x, temb, pooled, text)
+                x = blk.nhwc(x, temb, pooled, text, ra=nra())
             if slots:
                 # the skip has three consumers (next stage, two decoder blocks): their gradients are summed in one pass
                 x, s0, s1 = ops.fan3(x)
@@ -294,11 +337,11 @@ class UNet(nn.Module):
             else:
                 skips.append(x)
         if not slots:
-            x = self.middle_block.nhwc(x, temb, pooled, text)
+            x = self.middle_block.nhwc(x, temb, pooled, text, ra=nra())
             for lvl in (3, 2, 1, 0):
                 skip = skips.pop()
                 for blk in getattr(self, f"dec_block{lvl}"):
-                    x = blk.nhwc(torch.cat([x, skip], dim=-1), temb, pooled, text)   # same skip for both blocks (unet.py:480-504)
+                    x = blk.nhwc(torch.cat([x, skip], dim=-1), temb, pooled, text, ra=nra())   # same skip for both blocks (unet.py:480-504)
                 if lvl > 0:
                     up = getattr(self, f"upsample{lvl}")
                     x = ops.upsample_bilinear(x, up[0].size)
@@ -308,14 +351,14 @@ class UNet(nn.Module):
             # is copied into a [.., C1 + C2] buffer when that buffer is made, and the op that produces x writes it straight
             # into the other half (ops.ConcatSlot / ops.OutSlot) - half the concat's traffic, no CatArrayBatchedCopy.
             slot = ops.ConcatSlot(skips[-1][0], self.middle_block.res_block.out_channels)
-            x = self.middle_block.nhwc(x, temb, pooled, text, out=slot.out)
+            x = self.middle_block.nhwc(x, temb, pooled, text, out=slot.out, ra=nra())
             for lvl in (3, 2, 1, 0):
                 s0, s1 = skips.pop()
                 b0, b1 = getattr(self, f"dec_block{lvl}")
                 xc = slot.cat(x, s0)
                 slot = ops.ConcatSlot(s1, b0.res_block.out_channels)
-                x = b0.nhwc(xc, temb, pooled, text, out=slot.out)
-                x = b1.nhwc(slot.cat(x, s1), temb, pooled, text)
+                x = b0.nhwc(xc, temb, pooled, text, out=slot.out, ra=nra())
+                x = b1.nhwc(slot.cat(x, s1), temb, pooled, text, ra=nra())
                 if lvl > 0:
                     up = getattr(self, f"upsample{lvl}")
                     x = ops.upsample_bilinear(x, up[0].size)

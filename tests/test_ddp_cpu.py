@@ -214,3 +214,27 @@ def test_rank_generator_single_process_is_the_default_stream():
     assert rank_generator(torch.device("cpu")) is None                   # world 1: torch's default generator (reference behaviour)
     a, b = rank_generator(torch.device("cpu"), 0, 4), rank_generator(torch.device("cpu"), 3, 4)
     assert a.initial_seed() != b.initial_seed()
+
+
+def test_arena_layout_and_memory_order_buckets():
+    """An arena may place parameters in its own memory order (UNet.arena_layout: the 17 time_proj / text_proj weights adjacent
+    so that they are one GEMM operand); offsets stay indexed by PARAMETER, and the all-reduce buckets follow the memory order:
+    they tile the flat buffer and each parameter lies wholly inside its bucket."""
+    from pokemon_sprite_generator_amd.ddp import BucketedAllReduce
+    from pokemon_sprite_generator_amd.optim import _arena_offsets
+    shapes = [(64, 9), (64,), (130, 7), (8,), (1000, 33), (16,)]
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+    layout = [4, 1, 3, 5, 0, 2]
+    offsets, numel = _arena_offsets(params, layout)
+    assert offsets[4] == 0 and offsets[1] == 33000 and offsets[3] == 33064              # 8-element steps, layout order
+    assert _arena_offsets(params)[0] == [0, 576, 640, 1552, 1560, 34560]                # default: parameter order
+    with pytest.raises(ValueError):
+        _arena_offsets(params, [0, 1, 2, 3, 4, 4])
+    flat = torch.zeros(numel)
+    red = BucketedAllReduce(flat, params, offsets, bucket_bytes=1 << 12, overlap=False)
+    spans = sorted((s, e) for s, e, _ in red.buckets)
+    assert spans[0][0] == 0 and spans[-1][1] == numel and all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
+    for b, (s, e, mem) in enumerate(red.buckets):
+        for i in mem:
+            assert s <= offsets[i] and offsets[i] + params[i].numel() <= e and red._bucket_of[i] == b
+    assert sorted(i for _, _, mem in red.buckets for i in mem) == list(range(len(params)))
