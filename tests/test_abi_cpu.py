@@ -2,6 +2,7 @@
 declares; argument validation returns error codes (no compute is launched without a GPU)."""
 import ctypes as C
 import os
+import sys
 import re
 
 import pytest
@@ -112,7 +113,39 @@ def test_inline_asm_mfmas_have_no_valu_write_hazard(tmp_path):
                    check=True, capture_output=True, timeout=600)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "mfma_hazard_check.py"), asm, "wgrad_pipe_kernel"], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout[-2000:]
-    assert " 0 hazards" in r.stdout and not r.stdout.startswith("0 MFMAs"), r.stdout
+    assert " 0 hazards" in r.stdout and not r.stdout.startswith("0 inline-asm MFMAs"), r.stdout
+
+
+def test_mfma_hazard_checker_finds_planted_hazards():
+    """The checker's three classes on synthetic listings: A - VALU write of a source right in front of an
+    asm MFMA; B - a read of the MFMA's destination inside the write-back window (the accumulator drain too close); C - a source
+    that an LDS read wrote with no lgkmcnt wait in between.  And the clean forms of each pass."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import mfma_hazard_check as H
+
+    def run(body):
+        return H.check(("_Z6kernelv:\n" + body).split("\n"), "kernel")
+
+    mf = "\t;;#ASMSTART\n\tv_mfma_f32_16x16x32_bf16 a[0:3], v[10:13], v[20:23], a[0:3]\n\t;;#ASMEND\n"
+    n, f = run("\tv_mov_b32_e32 v10, 1.0\n" + mf)
+    assert n == 1 and len(f) == 1 and f[0].startswith("A "), f
+    n, f = run("\tv_mov_b32_e32 v10, 1.0\n\ts_nop 1\n\tv_add_u32_e32 v1, v2, v3\n" + mf)
+    assert n == 1 and not f, f
+    n, f = run(mf + "\ts_nop 3\n\tv_accvgpr_read_b32 v5, a2\n")
+    assert len(f) == 1 and f[0].startswith("B "), f
+    n, f = run(mf + "\ts_nop 15\n\tv_accvgpr_read_b32 v5, a2\n")
+    assert not f, f
+    n, f = run(mf + "\tv_mfma_f32_16x16x32_bf16 a[0:3], v[10:13], v[20:23], a[0:3]\n")        # back-to-back accumulation: interlocked
+    assert not f, f
+    n, f = run("\tds_read_b128 v[10:13], v40\n" + mf)
+    assert len(f) == 1 and f[0].startswith("C "), f
+    n, f = run("\tds_read_b128 v[10:13], v40\n\tds_read_b128 v[30:33], v41\n\ts_waitcnt lgkmcnt(1)\n" + mf)
+    assert not f, f
+    n, f = run("\tds_read_b128 v[30:33], v41\n\tds_read_b128 v[10:13], v40\n\ts_waitcnt lgkmcnt(1)\n" + mf)
+    assert len(f) == 1 and f[0].startswith("C "), f
+    # an MFMA the COMPILER issued (outside an asm block) is its own business: not counted, not flagged
+    n, f = run("\tv_mov_b32_e32 v10, 1.0\n\tv_mfma_f32_16x16x32_bf16 v[0:3], v[10:13], v[20:23], v[0:3]\n")
+    assert n == 0 and not f
 
 
 def test_workspace_pool_never_frees_a_buffer_a_graph_holds():

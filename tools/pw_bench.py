@@ -22,6 +22,8 @@ def timed(fn):
 
 shapes = [(50176, 640, 640), (50176, 640, 1280), (50176, 640, 1920), (50176, 1280, 640), (50176, 1920, 640), (12544, 1280, 1280),
           (12544, 1280, 3840), (12544, 1280, 2560), (12544, 2560, 1280), (8192, 1280, 2560)]
+if len(sys.argv) > 1 and sys.argv[1] == "longk":      # K as long as a 3x3 layer's: is the persistent form's K loop itself as fast as the per-tile kernel's?
+    shapes = [(50176, 5760, 640), (12544, 11520, 1280), (50176, 2560, 640)]
 print("%-22s %-14s %9s %9s %7s" % ("M,K,N", "form", "tiled us", "pw us", "gain"))
 tot = [0.0, 0.0]
 for M, K, N in shapes:
