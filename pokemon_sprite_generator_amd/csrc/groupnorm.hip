@@ -760,6 +760,22 @@ int psg_groupnorm_bwd_res(const void* dy, int64_t lddy, const void* x, int64_t l
         // 27x27 slabs run in 256 lanes, but measured no faster: 640 vs 648 us over the U-Net's eight shapes)
         int R = gn_fused_plan(f, dtype == PSG_BF16 ? 4 : 2, 256, 8);
         if (!R) R = gn_fused_plan(f, dtype == PSG_BF16 ? 4 : 2, 512, 8);
+        // These kernels wait on memory (round 4, rocprofv3: 50 % of the wave cycles; the LDS pipe is active 1 % of them, so its
+        // bank conflicts do not matter) and their slab rows are narrower than a 128-byte line (27x27x320: 40-byte rows, 3.1 TB/s;
+        // 14x14x640: 80 bytes, 4.5).  16-byte chunks double the row a (lanes x chunks) budget covers: with the bypass gradient
+        // as a third input stream -8...-20 % per launch (27x27x640 303 -> 267 us, 14x14x1280 143 -> 122), without it +-0
+        // (14x14x640 +10 %): taken for the bypass form only.
+        int NN = dtype == PSG_BF16 ? 4 : 2;
+        {
+            static int wide = -1;                          // PSG_GN_BWD_WIDE=0: 8-byte chunks only (A/B)
+            if (wide < 0) { const char* e = getenv("PSG_GN_BWD_WIDE"); wide = (e && atoi(e) == 0) ? 0 : 1; }
+            if (wide && dres && dtype == PSG_BF16 && R && f.slabC * 2 < 128) {
+                GnF f2 = f;
+                int R2 = gn_fused_plan(f2, 8, 256, 8);
+                if (!R2 || f2.slabC <= f.slabC) { f2 = f; R2 = gn_fused_plan(f2, 8, 512, 8); }
+                if (R2 && f2.slabC > f.slabC) { f = f2; R = R2; NN = 8; }
+            }
+        }
         const size_t lds = ((size_t)f.PP * f.slabC * 2 + 2 * (f.CCs * f.PP > f.slabC ? f.CCs * f.PP : f.slabC) + 4 * f.slabC + 4 * f.SG) * sizeof(float);
         if (R && lds <= 64 * 1024) {
             const dim3 g(B * f.nslab), t(f.CCs * f.PP);
@@ -769,6 +785,7 @@ int psg_groupnorm_bwd_res(const void* dy, int64_t lddy, const void* x, int64_t l
          else if (dres) hipLaunchKernelGGL((gn_bwd_fused_kernel<TT, NN, RR, false, true>), g, t, lds, s, f);    \
          else hipLaunchKernelGGL((gn_bwd_fused_kernel<TT, NN, RR, false, false>), g, t, lds, s, f); } while (0)
             if (dtype == PSG_F32) { if (R == 4) PSG_GN_BWD(float, 2, 4); else PSG_GN_BWD(float, 2, 8); }
+            else if (NN == 8) { if (R == 4) PSG_GN_BWD(bf16_t, 8, 4); else PSG_GN_BWD(bf16_t, 8, 8); }
             else { if (R == 4) PSG_GN_BWD(bf16_t, 4, 4); else PSG_GN_BWD(bf16_t, 4, 8); }
 #undef PSG_GN_BWD
             PSG_LAUNCH_CHECK("groupnorm_bwd_fused");
