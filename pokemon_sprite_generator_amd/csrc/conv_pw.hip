@@ -38,7 +38,9 @@ template <typename V> __device__ __forceinline__ void pw_tie(V& r) { asm volatil
 
 // EK: epilogue kind of conv_gemm_kernel.h.  HAS_AUX: a residual (added) or, for EK_DMUL, the saved derivative (multiplied).
 // HAS_PRE: second output tensor (`preact`: the pre-activation, or with PSG_CONV_SAVE_DACT the epilogue's derivative).
-template <int EK, bool HAS_AUX, bool HAS_PRE>
+// TR: the launch is a data gradient (transposed) - it only NAMES the instantiation, so that kernel traces and PMC summaries
+// (tools/pmc_summary.py) can put a launch into the forward or the data-gradient family; the code is the same.
+template <int EK, bool HAS_AUX, bool HAS_PRE, bool TR>
 __global__ __launch_bounds__(256, 2) void conv_pw_kernel(const ConvP p, const int total_tiles, const uint32_t aux_bytes) {
 #if defined(__HIP_DEVICE_COMPILE__)
     typedef bf16_t T;
@@ -294,7 +296,9 @@ static constexpr int PW_LDS = 2 * 256 * 128 + 4 * 16 * (64 * 2 + 16);
     X(EK_DMUL, true, false)
 
 int conv_pw_set_attrs() {
-#define X(EK, AUX, PRE) PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw_kernel<EK, AUX, PRE>), hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS));
+#define X(EK, AUX, PRE)                                                                                                                                   \
+    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw_kernel<EK, AUX, PRE, false>), hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS)); \
+    PSG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_pw_kernel<EK, AUX, PRE, true>), hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS));
     PSG_PW_FOR_ALL(X)
 #undef X
     return PSG_OK;
@@ -316,7 +320,8 @@ int launch_conv_pw(const ConvP& p0, hipStream_t stream) {
     bool done = false;
 #define X(EK, AUX, PRE)                                                                                                    \
     if (!done && ek == EK && aux == AUX && pre == PRE) {                                                                   \
-        hipLaunchKernelGGL((conv_pw_kernel<EK, AUX, PRE>), dim3(grid), dim3(256), PW_LDS, stream, p, total, aux_bytes);    \
+        if (p.transposed) hipLaunchKernelGGL((conv_pw_kernel<EK, AUX, PRE, true>), dim3(grid), dim3(256), PW_LDS, stream, p, total, aux_bytes); \
+        else hipLaunchKernelGGL((conv_pw_kernel<EK, AUX, PRE, false>), dim3(grid), dim3(256), PW_LDS, stream, p, total, aux_bytes);            \
         done = true;                                                                                                       \
     }
     PSG_PW_FOR_ALL(X)

@@ -27,6 +27,10 @@ def family(name):
         return "conv_gemm(fwd gather)" if m.group(3) in "02" else "conv_gemm(dgrad gather)"
     if "conv_gemm_kernel" in name:
         return "conv_gemm(?)"
+    m = re.search(r"conv_pw_kernel<[^>]*?(true|false)>\(|conv_pw_kernelI.*?Lb(\d)EEE", name)      # (<EK, AUX, PRE, TR>: TR names the family)
+    if m:
+        tr = (m.group(1) == "true") if m.group(1) else (m.group(2) == "1")
+        return "conv_gemm(dgrad gather)" if tr else "conv_gemm(fwd gather)"
     if "wgrad_kernel" in name or "wgrad_wide_kernel" in name or "wgrad_pipe_kernel" in name:
         return "wgrad"
     if "attn_" in name:
