@@ -1002,3 +1002,42 @@ def test_wgrad_pipe_tiles(psg, B, H, Cin, Cout, ks, with_bias):
         assert maxrel(wd.grad.cpu(), w.grad) < 1e-4 and rel_l2(wd.grad.cpu(), w.grad) < 1e-5, f"wgrad ({layout})"
         if with_bias:
             assert maxrel(bd.grad.cpu(), b.grad) < 1e-4, f"bias gradient ({layout})"
+
+
+def test_available_cus_changes_the_plan_not_the_result(psg):
+    """psg_set_available_cus (the planning input of the data-parallel overlap): with fewer CUs the
+    choosers pick other tiles / split counts - the results stay those of the same GEMM (fp32 accumulation order aside) - and
+    a CU-masked stream (psg_stream_create_cu_mask) runs the same launches."""
+    from pokemon_sprite_generator_amd import _lib, ops
+    lib = _lib.init(0)
+    torch.manual_seed(3)
+    x = torch.randn(64, 14, 14, 640, device=DEV).bfloat16().requires_grad_(True)
+    w = (torch.randn(640, 640, 3, 3, device=DEV) * 0.02).requires_grad_(True)
+    gy = torch.randn(64, 14, 14, 640, device=DEV).bfloat16()
+
+    def run():
+        xs, ws = x.detach().clone().requires_grad_(True), w.detach().clone().requires_grad_(True)
+        y = ops.conv2d(xs, ws)
+        y.backward(gy)
+        torch.cuda.synchronize()
+        return y.detach().float(), xs.grad.float(), ws.grad.float()
+
+    ref = run()
+    sp = C.c_void_p()
+    try:
+        _lib.set_available_cus(0, 96)
+        got = run()
+        _lib.check(lib.psg_stream_create_cu_mask(96, C.byref(sp)), "psg_stream_create_cu_mask")
+        ext = torch.cuda.ExternalStream(sp.value, device=torch.device(DEV, 0))
+        ext.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(ext):
+            masked = run()
+        torch.cuda.current_stream().wait_stream(ext)
+    finally:
+        _lib.set_available_cus(0, 0)
+        torch.cuda.synchronize()
+        if sp.value:
+            _lib.check(lib.psg_stream_destroy(sp), "psg_stream_destroy")
+    for a, b, c in zip(ref, got, masked):
+        assert rel_l2(b, a) < 2e-3 and rel_l2(c, a) < 2e-3, (rel_l2(b, a), rel_l2(c, a))
+    assert lib.psg_set_available_cus(5) != 0                      # (out of range: an error code, not a crash)

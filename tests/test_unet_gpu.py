@@ -634,3 +634,56 @@ def test_gradient_batch_linearity_b256():
     assert worst < 4e-2, (worst_name, worst)      # the bf16 bar of the batch-64 test
     assert len(zero) == 0, zero
     st.close()
+
+
+def test_proj_group_matches_per_block_projections():
+    """ops.ProjGroup (the 17 ResBlocks' time_proj / text_proj as two GEMMs over virtual parameters, round 4) against the
+    per-block form (`unet._PROJ_GROUP = False`): same prediction, and the gradients of the 68 real parameters - written
+    through runs of the gradient arena - agree per parameter (fp32: summation order only); the arena layout really puts each
+    kind's weights next to each other, and the data-parallel bookkeeping sees all of them as written."""
+    import pokemon_sprite_generator_amd as psg
+    import pokemon_sprite_generator_amd.unet as U
+    from pokemon_sprite_generator_amd import ops
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev).manual_seed(21)
+    lat = torch.randn(2, 8, 27, 27, device=dev, generator=g)
+    txt = torch.randn(2, 32, 256, device=dev, generator=g)
+    t = torch.tensor([17, 801], device=dev)
+    nz = torch.randn(2, 8, 27, 27, device=dev, generator=g)
+    res = {}
+    old = U._PROJ_GROUP
+    try:
+        for mode in (True, False):
+            U._PROJ_GROUP = mode
+            torch.manual_seed(0)
+            unet = psg.UNet(compute_dtype=torch.float32).to(dev)
+            with torch.no_grad():
+                for name, p in unet.named_parameters():
+                    if p.dim() == 2 and ("time_proj" in name or "text_proj" in name):
+                        p.mul_(25.0)                      # (default init hides these branches)
+            st = psg.DiffusionStepper(unet, psg.NoiseScheduler(), distributed=False)
+            assert (unet._proj_group is not None) == mode
+            unet.eval()
+            loss = _fwd_bwd(psg, unet, st, lat, txt, t, nz)
+            names = [n for n, p in unet.named_parameters() if p.requires_grad]
+            grads = {n: st.arena.flat[o:o + p.numel()].clone() for (n, p), o in
+                     zip([(n, p) for n, p in unet.named_parameters() if p.requires_grad], st.arena.offsets)}
+            if mode:
+                # layout: the 17 time_proj weights form one contiguous run at the head of the arena, in block order
+                idx = [i for i, n in enumerate(names) if n.endswith("res_block.time_proj.weight")]
+                offs = [st.arena.offsets[i] for i in idx]
+                assert offs[0] == 0 and offs == sorted(offs) and len(idx) == 17
+                assert all(e.written for e in st.arena.entries), "a member parameter was not marked written"
+            res[mode] = (loss, grads)
+            st.close()
+            del st, unet
+    finally:
+        U._PROJ_GROUP = old
+    (l1, g1), (l0, g0) = res[True], res[False]
+    assert abs(l1 - l0) < 1e-6 * max(1.0, abs(l0))
+    worst = 0.0
+    for n in g0:
+        nb = float(g0[n].double().norm())
+        assert nb > 0, n
+        worst = max(worst, float((g1[n].double() - g0[n].double()).norm()) / nb)
+    assert worst < 1e-4, worst
