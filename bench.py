@@ -537,6 +537,7 @@ def run_worker(args):
             res["allreduce_buckets_launched_during_backward"] = stepper.reducer.launched_early
             res["allreduce_avg_in_collective"] = stepper.reducer.avg_in_collective
             res["allreduce_mode"] = {"overlap": bool(stepper.reducer.overlap), "cu_reserve": stepper.reducer.cu_reserve,
+                                     "reserve_rounds": stepper.reducer.reserve_rounds,
                                      "rccl_max_channels": os.environ.get("NCCL_MAX_NCHANNELS"), "tuned": stepper.reducer.tuned}
         if force_ddp:
             res["force_ddp"] = "process group of ONE rank over RCCL: every collective of the data-parallel step executes (identity exchange)"

@@ -353,6 +353,9 @@ int psg_clip_scale_f32(float* g, int64_t n, const float* normsq, float max_norm,
  * 256 = the whole MI355X; 0 restores it).  A data-parallel step that overlaps the RCCL all-reduce with backward sets it to
  * 256 minus the CUs the collective's channels occupy, so a launch planned as ONE round of workgroups does not become two. */
 int psg_set_available_cus(int n);
+/* ... r > 0: only launches that would take at most r rounds of workgroups on the whole chip plan around the reserve (a
+ * one-round grid doubles when CUs are taken; a many-round grid loses the CU share either way); 0: every launch (default). */
+int psg_set_reserve_rounds(int r);
 /* Measurement helpers (tools/contention.py): a HIP stream restricted to n_cus CUs (hipExtStreamCreateWithCUMask; the CUs
  * taken out are spread evenly over the 8 XCDs), to rehearse the step with part of the chip occupied by a collective. */
 int psg_stream_create_cu_mask(int n_cus, psg_stream_t* stream);

@@ -100,6 +100,7 @@ SIGNATURES = {
     "psg_adamw_dev_f32": (c_int, [c_void_p] * 4 + [c_int64, c_void_p, c_void_p, c_int] + [c_float] * 4 + [c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p]),
     "psg_clip_scale_f32": (c_int, [c_void_p, c_int64, c_void_p, c_float, c_void_p]),
     "psg_set_available_cus": (c_int, [c_int]),
+    "psg_set_reserve_rounds": (c_int, [c_int]),
     "psg_stream_create_cu_mask": (c_int, [c_int, c_void_p]),
     "psg_stream_destroy": (c_int, [c_void_p]),
     "psg_profile_begin": (c_int, []),
@@ -147,13 +148,15 @@ def init(device_index: int):
     return lib
 
 
-AVAIL_CUS = [256]                        # mirror of psg_set_available_cus (ops caches split-K plans per value)
+AVAIL_CUS = [256, 0]                     # mirror of (psg_set_available_cus, psg_set_reserve_rounds): ops caches split-K plans per value
 
 
-def set_available_cus(device_index: int, n: int):
-    """psg_set_available_cus + the host-side mirror (n = 0: the whole chip)."""
-    check(init(device_index).psg_set_available_cus(int(n)), "psg_set_available_cus")
-    AVAIL_CUS[0] = 256 if n == 0 else int(n)
+def set_available_cus(device_index: int, n: int, rounds: int = 0):
+    """psg_set_available_cus (+ psg_set_reserve_rounds) and the host-side mirror (n = 0: the whole chip)."""
+    lib = init(device_index)
+    check(lib.psg_set_available_cus(int(n)), "psg_set_available_cus")
+    check(lib.psg_set_reserve_rounds(int(rounds)), "psg_set_reserve_rounds")
+    AVAIL_CUS[0], AVAIL_CUS[1] = (256 if n == 0 else int(n)), int(rounds)
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)

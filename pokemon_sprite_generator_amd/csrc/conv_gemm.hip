@@ -32,7 +32,8 @@ static ConvPlan conv_plan(const ConvP& p, int dtype, bool may_split) {
     // (a K <= 640 boost for 128x64 - three resident workgroups hiding the short loop ends - paid before the epilogue was
     //  specialised per kind; since then 128x128 wins those layers by 10 %: gemm_direct.py)
     if (dtype != PSG_BF16 || p.ntap > 0) eff[3] = eff[4] = 0.0;   // 160 = 2 x 5 x 16: only the 16x16x32 bf16 tiles divide it
-    const double slots = 2.0 * avail_cus();            // resident workgroups on the chip (2 per CU; psg_set_available_cus)
+    // resident workgroups on the chip (2 per CU; psg_set_available_cus / psg_set_reserve_rounds)
+    const double slots = 2.0 * avail_cus_for((double)((M + 127) / 128) * (double)((p.N + 127) / 128) / 512.0);
     double best = -1.0;
     for (int c = 0; c < 5; ++c) {
         const double tiles = (double)((M + cand[c][0] - 1) / cand[c][0]) * (double)((p.N + cand[c][1] - 1) / cand[c][1]);

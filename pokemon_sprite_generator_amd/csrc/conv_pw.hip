@@ -277,7 +277,7 @@ bool conv_pw_applicable(const ConvP& p, int dtype) {
     if (pw_kind(p) < 0) return false;
     if (p.dact_u && p.residual) return false;
     const int64_t tiles = (int64_t)(p.M / 128) * (p.N / 128);
-    if (tiles < 3 * (int64_t)avail_cus()) return false;   // (1.5 tiles per resident slot: most workgroups get a second tile)
+    if (tiles < 3 * (int64_t)avail_cus_for((double)tiles / 512.0)) return false;   // (1.5 tiles per resident slot: most workgroups get a second tile)
     const void* aux = p.dact_u ? p.dact_u : p.residual;
     if (aux) {
         const int64_t ld = p.dact_u ? p.lddact : p.ldres;
@@ -308,7 +308,7 @@ int launch_conv_pw(const ConvP& p0, hipStream_t stream) {
     ConvP p = p0;
     p.mtiles = p.M / 128; p.ntiles = p.N / 128;
     const int total = p.mtiles * p.ntiles;
-    int grid = 2 * avail_cus();
+    int grid = 2 * avail_cus_for((double)total / 512.0);
     if (grid > total) grid = total;
     grid &= ~7;                                          // (a virtual block keeps its XCD: v and v + G agree mod 8)
     const int ek = pw_kind(p);

@@ -39,7 +39,9 @@ ProfScope::~ProfScope() {
 }
 
 static int g_avail_cus = 256;
+static int g_reserve_rounds = 0;
 int avail_cus() { return g_avail_cus; }
+int avail_cus_for(double rounds_full) { return (g_reserve_rounds > 0 && rounds_full > (double)g_reserve_rounds) ? 256 : g_avail_cus; }
 
 }  // namespace psg
 using namespace psg;
@@ -49,6 +51,12 @@ extern "C" {
 int psg_set_available_cus(int n) {
     PSG_REQUIRE(n == 0 || (n >= 8 && n <= 256), PSG_ERR_ARG, "set_available_cus: %d", n);
     g_avail_cus = n == 0 ? 256 : n;
+    return PSG_OK;
+}
+
+int psg_set_reserve_rounds(int r) {
+    PSG_REQUIRE(r >= 0 && r <= 64, PSG_ERR_ARG, "set_reserve_rounds: %d", r);
+    g_reserve_rounds = r;
     return PSG_OK;
 }
 

@@ -49,6 +49,10 @@ struct ProfScope {
 // CUs the tile choosers may count on (psg_set_available_cus; 256 unless part of the chip is taken, e.g. by an overlapped
 // RCCL all-reduce): a launch planned as ONE round of workgroups over 256 CUs becomes two when 16 of them are busy
 int avail_cus();
+// ... for a launch that would take `rounds_full` rounds of workgroups on the whole chip: with psg_set_reserve_rounds(r > 0) only
+// launches of at most r rounds plan around the reserve (a one-round grid becomes two when CUs are taken: 2x; a ten-round
+// grid loses 14 % either way, and planning it for fewer CUs costs that 14 % also while the CUs are free)
+int avail_cus_for(double rounds_full);
 
 static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 static inline bool aligned8(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 7) == 0; }

@@ -991,6 +991,8 @@ static void wgrad_plan(const psg_wgrad_desc* d, WgP& p) {
         const int64_t tiles128 = (int64_t)((d->Cout + 127) / 128) * ((p.Q + 127) / 128);
         if (!off && d->dtype == PSG_BF16 && same && p.BR == 128 && q256 * 100 <= (int64_t)p.Q * 105 && tiles128 >= 200) { p.wide = 1; BKP = 32; }
     }
+    // (a weight gradient's tile count is small and its split count is chosen to fill the chip in ONE or two rounds: it always
+    //  plans around the reserve)
     int kSlots = 2 * avail_cus();
     {
         // pipelined 320 x 192 tiles (one 256-thread workgroup per CU, wgrad_pipe_kernel): 320 divides Cout, the 192-column grid

@@ -25,6 +25,11 @@ import torch.distributed as dist
 # dispatcher deals workgroups round-robin over 8 XCDs x 4 shader engines, so the reserve is a whole CU per engine (32), and
 # RCCL is capped at that many channels (`configure_rccl`, before init_process_group).
 CU_RESERVE = int(os.environ.get("PSG_DDP_CU_RESERVE", "32"))
+# ... and which launches plan around it: those of at most this many rounds of workgroups on the whole chip (0: all).  A one-round
+# grid takes twice as long when CUs are missing, a ten-round grid 14 % longer whatever the plan - and planning it for 224 CUs
+# costs those 14 % also while the CUs are free (at world size 1, nothing taken: +5.6 % of the step with every launch planned
+# for 224 CUs).
+RESERVE_ROUNDS = int(os.environ.get("PSG_DDP_RESERVE_ROUNDS", "3"))
 
 
 def configure_rccl(max_channels=None):
@@ -151,6 +156,7 @@ class BucketedAllReduce:
                  bucket_dtype=torch.float32, force_single=False, cu_reserve=None):
         self.flat = arena_flat
         self.cu_reserve = CU_RESERVE if cu_reserve is None else int(cu_reserve)
+        self.reserve_rounds = RESERVE_ROUNDS
         self._cus_set = False
         self.tuned = None                  # autotune()'s record
         self.group = process_group
@@ -209,21 +215,24 @@ class BucketedAllReduce:
 
     def autotune(self, run_step, trials=3):
         """Choose HOW the exchange runs on this machine by measuring it (the answer depends on how many CUs RCCL's channels
-        take and on the links - unknowable on a 1-GPU box): `run_step()` executes one full train step; three settings are
-        timed, `trials` steps each after one untimed step: buckets overlapped with backward and tiles planned around the CU
-        reserve ("overlap+reserve"), overlapped with plans for the whole chip ("overlap"), and the whole exchange after backward
-        ("deferred": no contention, nothing hidden).  Ranks agree through a MAX all-reduce of the times (the job runs at the
+        take and on the links - unknowable on a 1-GPU box): `run_step()` executes one full train step; four settings are
+        timed, `trials` steps each after one untimed step: buckets overlapped with backward and EVERY launch planned around the CU
+        reserve ("overlap+reserve"), only the launches of few rounds planned around it ("overlap+reserve-few-rounds"),
+        overlapped with plans for the whole chip ("overlap"), and the whole exchange after backward ("deferred": no contention,
+        nothing hidden).  Ranks agree through a MAX all-reduce of the times (the job runs at the
         pace of its slowest rank) and all take the same fastest setting.  Returns the record (also kept in `.tuned`)."""
         if not self.active:
             return None
-        settings = [("overlap+reserve", True, self.cu_reserve), ("overlap", True, 0), ("deferred", False, 0)]
+        rr = self.reserve_rounds if self.reserve_rounds > 0 else 3
+        settings = [("overlap+reserve", True, self.cu_reserve, 0), ("overlap+reserve-few-rounds", True, self.cu_reserve, rr),
+                    ("overlap", True, 0, 0), ("deferred", False, 0, 0)]
         if self.cu_reserve <= 0 or self._stream is None:
-            settings = [x for x in settings if x[0] != "overlap+reserve"]
+            settings = [x for x in settings if not x[0].startswith("overlap+reserve")]
         if self._stream is None:
             settings = [x for x in settings if x[1] is False]
         times = []
-        for name, ov, res in settings:
-            self.overlap, self.cu_reserve = ov and self._stream is not None, res
+        for name, ov, res, rounds in settings:
+            self.overlap, self.cu_reserve, self.reserve_rounds = ov and self._stream is not None, res, rounds
             run_step()
             if self.flat.is_cuda:
                 torch.cuda.synchronize()
@@ -237,8 +246,8 @@ class BucketedAllReduce:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=self.group)
         tl = [float(x) for x in tt.tolist()]
         best = min(range(len(tl)), key=lambda i: tl[i])
-        name, ov, res = settings[best]
-        self.overlap, self.cu_reserve = ov and self._stream is not None, res
+        name, ov, res, rounds = settings[best]
+        self.overlap, self.cu_reserve, self.reserve_rounds = ov and self._stream is not None, res, rounds
         self.tuned = {"chosen": name, "ms_per_step": {settings[i][0]: 1e3 * tl[i] for i in range(len(tl))}, "trials": trials}
         return self.tuned
 
@@ -275,7 +284,7 @@ class BucketedAllReduce:
             return
         from . import _lib
         _lib.set_available_cus(self.flat.device.index if self.flat.device.index is not None else torch.cuda.current_device(),
-                               0 if reserve <= 0 else 256 - int(reserve))
+                               0 if reserve <= 0 else 256 - int(reserve), self.reserve_rounds if reserve > 0 else 0)
         self._cus_set = reserve > 0
 
     def _launch(self, b):

@@ -290,7 +290,7 @@ def _conv_launch(lib, dtype, x, ldx, w, ldw, y, ldy, geom, Cin, Cout, transposed
     # small grids (sampling, small batches): offer a split-K workspace.  Only launches with few output elements are asked
     # about (one plan evaluation on the host); a batch-256 train step never is.
     if B * Ho * Wo * Cout <= _SPLITK_MAX_OUT and _SPLITK:
-        key = (dtype, geom, Cin, Cout, transposed, _lib.AVAIL_CUS[0])
+        key = (dtype, geom, Cin, Cout, transposed, _lib.AVAIL_CUS[0], _lib.AVAIL_CUS[1])
         need = _splitk_need.get(key)
         if need is None:
             need = _splitk_need[key] = lib.psg_conv_fwd_workspace_bytes(cp)

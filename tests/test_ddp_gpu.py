@@ -279,7 +279,7 @@ def test_bench_rehearsal_two_ranks_one_gpu():
     # the start-up measurement chose how the exchange runs (over gloo through the host the overlapped form usually loses);
     # whichever it chose is what the timed steps did (the overlap plumbing itself: test_full_width_two_rank_step)
     mode = j["allreduce_mode"]
-    assert set(mode["tuned"]["ms_per_step"]) == {"overlap+reserve", "overlap", "deferred"} and mode["tuned"]["chosen"] in mode["tuned"]["ms_per_step"]
+    assert set(mode["tuned"]["ms_per_step"]) == {"overlap+reserve", "overlap+reserve-few-rounds", "overlap", "deferred"} and mode["tuned"]["chosen"] in mode["tuned"]["ms_per_step"]
     if mode["overlap"]:
         assert j["allreduce_buckets_launched_during_backward"] >= j["allreduce_buckets"] - 1
     else:
@@ -375,7 +375,7 @@ def test_rccl_world1_step_is_the_single_process_step(bucket_dtype, full):
         assert r["params_equal"] and r["gnorm0"] == r["gnorm1"]
     if not full:
         tn = r["tuned"]
-        assert tn["chosen"] in tn["ms_per_step"] and set(tn["ms_per_step"]) == {"overlap+reserve", "overlap", "deferred"}, tn
+        assert tn["chosen"] in tn["ms_per_step"] and set(tn["ms_per_step"]) == {"overlap+reserve", "overlap+reserve-few-rounds", "overlap", "deferred"}, tn
 
 
 def test_bench_force_ddp_runs_rccl_on_one_gpu():

@@ -25,8 +25,8 @@ for ncu in (256, 240, 224, 192):
     sp = C.c_void_p()
     _lib.check(lib.psg_stream_create_cu_mask(ncu, C.byref(sp)), "psg_stream_create_cu_mask")
     ext = torch.cuda.ExternalStream(sp.value, device=dev)
-    for plan in (("blind", 256), ("matched", ncu)) if ncu != 256 else (("blind", 256),):
-        _lib.set_available_cus(0, 0 if plan[1] == 256 else plan[1])
+    for plan in (("blind", 256, 0), ("matched", ncu, 0), ("matched, <= 3 rounds", ncu, 3)) if ncu != 256 else (("blind", 256, 0), ("plan 224", 224, 0), ("plan 224, <= 3 rounds", 224, 3)):
+        _lib.set_available_cus(0, 0 if plan[1] == 256 else plan[1], plan[2])
         ext.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(ext):
             for _ in range(2):
