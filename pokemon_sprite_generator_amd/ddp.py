@@ -231,17 +231,26 @@ class BucketedAllReduce:
         if self._stream is None:
             settings = [x for x in settings if x[1] is False]
         times = []
-        for name, ov, res, rounds in settings:
-            self.overlap, self.cu_reserve, self.reserve_rounds = ov and self._stream is not None, res, rounds
-            run_step()
-            if self.flat.is_cuda:
-                torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(trials):
+        start = (self.overlap, self.cu_reserve, self.reserve_rounds)
+        try:
+            for name, ov, res, rounds in settings:
+                self.overlap, self.cu_reserve, self.reserve_rounds = ov and self._stream is not None, res, rounds
                 run_step()
-            if self.flat.is_cuda:
-                torch.cuda.synchronize()
-            times.append((time.perf_counter() - t0) / trials)
+                if self.flat.is_cuda:
+                    torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(trials):
+                    run_step()
+                if self.flat.is_cuda:
+                    torch.cuda.synchronize()
+                times.append((time.perf_counter() - t0) / trials)
+        except BaseException:
+            # a step failed mid-measurement: leave the reducer as it was configured (and the planners on the whole chip)
+            self.overlap, self.cu_reserve, self.reserve_rounds = start
+            self.reset()
+            if self._cus_set:
+                self._plan_cus(0)
+            raise
         tt = torch.tensor(times, dtype=torch.float64, device=self.flat.device if dist.get_backend(self.group) == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX, group=self.group)
         tl = [float(x) for x in tt.tolist()]
