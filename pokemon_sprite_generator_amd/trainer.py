@@ -202,6 +202,28 @@ class DiffusionStepper:
             raise NotImplementedError("capture_train_step needs the fused optimizer (device-side step count)")
         return GraphedTrainStep(self, latents, text_emb, t, warmup)
 
+    def autotune_exchange(self, latents, text_emb, t, trials=3):
+        """Data parallel: measure which gradient-exchange mode is fastest on THIS machine (ddp.BucketedAllReduce.autotune: real
+        train steps on the given batch, every rank takes part) WITHOUT training - masters, moments, step count and the bf16
+        shadow are snapshotted (10 GB at full width) and put back, so the model, the optimizer and the schedule are exactly
+        where they were; only the random streams have moved on.  Returns the record (None in a single process)."""
+        if self.reducer is None or not self.reducer.active or not isinstance(self.optimizer, FusedAdamW):
+            return None
+        opt = self.optimizer
+        snap = (self.params.flat.clone(), opt._m.clone(), opt._v.clone(), opt.step_dev.clone(),
+                None if self.params.shadow is None else self.params.shadow.clone())
+        try:
+            rec = self.reducer.autotune(lambda: self.train_step(latents, text_emb, t), trials=trials)
+        finally:
+            with torch.no_grad():
+                self.params.flat.copy_(snap[0]); opt._m.copy_(snap[1]); opt._v.copy_(snap[2]); opt.step_dev.copy_(snap[3])
+                if snap[4] is not None:
+                    self.params.shadow.copy_(snap[4])
+            ops_mod.WeightCache.invalidate()
+            if self.params.shadow is not None:
+                self.params.mark_shadow_current()
+        return rec
+
     def steps_done(self) -> int:
         """Optimizer steps that really happened (host sync for the fused optimizer)."""
         return self.optimizer.steps_done() if isinstance(self.optimizer, FusedAdamW) else self.host_steps
@@ -450,6 +472,8 @@ class ImprovedDiffusionTrainer:
         self.vae_dtype = {"bf16": torch.bfloat16, "bfloat16": torch.bfloat16, "fp32": torch.float32,
                           "float32": torch.float32}[str(mi.get("vae_dtype", "fp32"))]
         self._grad_bucket_dtype = {"fp32": torch.float32, "bf16": torch.bfloat16}[str(mi.get("grad_bucket_dtype", "fp32"))]
+        # data parallel: measure the gradient-exchange mode on the first training batch (state is restored: no training happens)
+        self._ddp_autotune = bool(mi.get("ddp_autotune", True))
         if not torch.cuda.is_available():
             raise _lib.PsgError("ImprovedDiffusionTrainer (MI355X build) needs a GPU; there is no CPU fallback")
         self.device = torch.device("cuda", torch.cuda.current_device())
@@ -680,6 +704,11 @@ class ImprovedDiffusionTrainer:
             try:
                 latent, text_emb, pre = self._encode(batch)
                 t = self.stepper.randint_t(latent.shape[0])
+                if self._ddp_autotune and self.world > 1:
+                    self._ddp_autotune = False
+                    rec = self.stepper.autotune_exchange(latent, text_emb, t)
+                    if rec is not None and self.is_main:
+                        self.logger.info(f"gradient exchange mode: {rec['chosen']} ({rec['ms_per_step']})")
                 out = self.train_step(latent, text_emb, t, pre_flag=pre)
                 flag = out["nan_flag"]
                 good = (flag & FLAG_SKIP_MASK) == 0

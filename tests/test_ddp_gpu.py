@@ -337,12 +337,17 @@ def _rccl_world1_worker(port, q, bucket_dtype, full):
         loss1, flag1, gnorm1 = float(out1["loss"].item()), int(out1["nan_flag"].item()), float(out1["grad_norm"].item())
         early, steps1 = red.launched_early, st1.steps_done()   # (of the step above: the measurement below runs more steps, on other settings)
         tuned = None
-        if not full:                                 # the start-up measurement that picks the exchange mode runs real steps
+        restored = None
+        if not full:                                 # the start-up measurement that picks the exchange mode runs real steps ...
             lat, txt, t, nz = _batch()
             red.cu_reserve = 32
-            tuned = red.autotune(lambda: st1.train_step(lat.cuda(), txt.cuda(), t.cuda(), nz.cuda()), trials=2)
+            before = (st1.params.flat.clone(), st1.optimizer._m.clone(), st1.optimizer._v.clone(), st1.steps_done())
+            tuned = st1.autotune_exchange(lat.cuda(), txt.cuda(), t.cuda(), trials=2)
+            # ... and leaves the model, the moments and the step count exactly where they were
+            restored = bool(torch.equal(st1.params.flat, before[0]) and torch.equal(st1.optimizer._m, before[1])
+                            and torch.equal(st1.optimizer._v, before[2]) and st1.steps_done() == before[3])
         g1, p1 = g1c, p1c
-        q.put({"ok": True, "tuned": tuned, "backend": dist.get_backend(), "world": red.world, "active": red.active, "avg": red.avg_in_collective,
+        q.put({"ok": True, "tuned": tuned, "restored": restored, "backend": dist.get_backend(), "world": red.world, "active": red.active, "avg": red.avg_in_collective,
                "buckets": len(red.buckets), "early": early, "bytes": red.bytes_per_step, "numel": int(st1.arena.numel),
                "grads_equal": bool(torch.equal(g1, want)), "grad_err": float((g1 - want).abs().max()),
                "params_equal": bool(torch.equal(p1, p0)) if bucket_dtype == "fp32" else None,
@@ -374,6 +379,7 @@ def test_rccl_world1_step_is_the_single_process_step(bucket_dtype, full):
     if bucket_dtype == "fp32":
         assert r["params_equal"] and r["gnorm0"] == r["gnorm1"]
     if not full:
+        assert r["restored"] is True
         tn = r["tuned"]
         assert tn["chosen"] in tn["ms_per_step"] and set(tn["ms_per_step"]) == {"overlap+reserve", "overlap+reserve-few-rounds", "overlap", "deferred"}, tn
 
