@@ -134,6 +134,8 @@ __global__ __launch_bounds__(256, (ND <= 5 ? 2 : 1)) void attn_fwd_mfma(const At
 #pragma unroll
             for (int e = 0; e < 16; ++e) oacc[t][e] = 0.f;
         float m = -INFINITY, lsum = 0.f;
+        const DropRow dr = drop_row(seed, ((uint64_t)bh * p.L + l) * (uint64_t)((p.S + 1) >> 1));
+        const uint32_t t16 = p.drop_thresh >> 16;
         for (int kt = 0; kt < nkt; ++kt) {
             f32x16 st;
 #pragma unroll
@@ -144,11 +146,16 @@ __global__ __launch_bounds__(256, (ND <= 5 ? 2 : 1)) void attn_fwd_mfma(const At
                 st = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], st, 0, 0, 0);
             }
             float mx = -INFINITY;
+            if (kt * 32 + 32 <= p.S) {                     // (wave-uniform) a full key tile: nothing to mask
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kt * 32 + acc_row(r, fh);
-                st[r] = key < p.S ? st[r] * p.scale : -INFINITY;
-                mx = fmaxf(mx, st[r]);
+                for (int r = 0; r < 16; ++r) { st[r] = st[r] * p.scale; mx = fmaxf(mx, st[r]); }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kt * 32 + acc_row(r, fh);
+                    st[r] = key < p.S ? st[r] * p.scale : -INFINITY;
+                    mx = fmaxf(mx, st[r]);
+                }
             }
             mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
             const float mn = fmaxf(m, mx);
@@ -159,13 +166,13 @@ __global__ __launch_bounds__(256, (ND <= 5 ? 2 : 1)) void attn_fwd_mfma(const At
             lsum = lsum * alpha + ps;
             m = mn;
             if (p.drop_thresh) {
-                const uint64_t prow = ((uint64_t)bh * p.L + l) * (uint64_t)((p.S + 1) >> 1);
+                // Branch-free (as in the dQ kernel): an absent key's probability is already exp(-inf) = 0 and an absent query's
+                // column is never stored, so neither needs a test here.
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {          // registers r, r+1 hold keys 2k, 2k+1: one hash for both
-                    const int key = kt * 32 + acc_row(r, fh);
-                    const uint32_t hh = drop_hash_pair(seed, prow + (uint32_t)(key >> 1));
-                    st[r] = (lok && key < p.S && drop_keep_half(hh, 0, p.drop_thresh)) ? st[r] * p.drop_scale : 0.f;
-                    st[r + 1] = (lok && key + 1 < p.S && drop_keep_half(hh, 1, p.drop_thresh)) ? st[r + 1] * p.drop_scale : 0.f;
+                    const uint32_t hh = drop_hash_row(dr, (uint32_t)(kt * 16 + (acc_row(r, fh) >> 1)));
+                    st[r] = (hh & 0xFFFFu) >= t16 ? st[r] * p.drop_scale : 0.f;
+                    st[r + 1] = (hh >> 16) >= t16 ? st[r + 1] * p.drop_scale : 0.f;
                 }
             }
 #pragma unroll
@@ -416,7 +423,18 @@ __global__ __launch_bounds__(256, (ND <= 5 ? 2 : 1)) void attn_dkv_mfma(const At
             const uint32_t hS = (uint32_t)((p.S + 1) >> 1), koff = (uint32_t)(key >> 1);
             const DropRow dr = drop_row(seed, ((uint64_t)bh * p.L + (uint64_t)(qt * 32)) * (uint64_t)hS);
             const uint32_t t16 = p.drop_thresh >> 16;
-            const int hsh = (key & 1) ? 16 : 0;
+            const int odd = key & 1, hsh = odd ? 16 : 0;
+            // The lanes of keys 2k, 2k+1 (lane ^ 1: same key pair, same query rows) need the SAME 16 pair hashes: each computes
+            // eight (rows 8 odd ... 8 odd + 7 of the register order) and takes the other eight from its neighbour (DPP quad
+            // permute [1,0,3,2]) - the hash is three integer multiplies, the exchange one move.
+            uint32_t hmine[8], hpeer[8];
+            if (p.drop_thresh) {                           // (wave-uniform)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    hmine[j] = drop_hash_row(dr, (uint32_t)(acc_row(j, fh) + 16 * odd) * hS + koff);   // acc_row(8 odd + j) = acc_row(j) + 16 odd
+                    hpeer[j] = (uint32_t)__builtin_amdgcn_mov_dpp((int)hmine[j], 0xB1, 0xF, 0xF, false);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int l = qt * 32 + acc_row(r, fh);
@@ -424,7 +442,7 @@ __global__ __launch_bounds__(256, (ND <= 5 ? 2 : 1)) void attn_dkv_mfma(const At
                 const float pr = __expf(st[r] * p.scale - ld2.x);
                 float dpr = dp[r], pv = pr;
                 if (p.drop_thresh) {                       // (wave-uniform)
-                    const uint32_t hh = drop_hash_row(dr, (uint32_t)acc_row(r, fh) * hS + koff);
+                    const uint32_t hh = ((r >> 3) == odd) ? hmine[r & 7] : hpeer[r & 7];
                     const bool keep = ((hh >> hsh) & 0xFFFFu) >= t16;
                     pv = keep ? pr * p.drop_scale : 0.f;
                     dpr = keep ? dpr * p.drop_scale : 0.f;
